@@ -1,0 +1,179 @@
+"""Weight containers for the HIP detector.
+
+* `seeded_checkpoint(scale, nc, seed)`  -- deterministic random-init YOLOv8 weights in the ultralytics
+  state_dict layout (conv weight + BatchNorm gamma/beta/mean/var).  No trained weights ship with the
+  reference (README.md:192-206 are download links; test/run_inference.sh:4 names a file that is not in
+  the repo), so every config here runs on these.
+* `fold(checkpoint)`                   -- Conv2d(bias=False)+BatchNorm2d(eps=1e-3) -> conv weight + bias, fp32
+  (what ultralytics `fuse()` does before inference).
+* `write_cyw(path, ...)` / `read_cyw(path)` -- the flat "CYW1" file the C-ABI loads with `cy_load_weights`.
+
+CYW1 layout (little endian):
+  "CYW1" u32 version=1 | char scale[4] | u32 nc | u32 nconv | u32 nnames
+  nnames x { u32 len | bytes (padded to 4) }
+  nconv  x { u32 cout cin k s act | u32 name_len | name (padded to 4) | f32 W[cout][cin][k][k] | f32 b[cout] }
+"""
+import json
+import os
+import struct
+import numpy as np
+from . import yolov8_spec as S
+
+BN_EPS = 1e-3
+# class-logit bias of the detect head for seeded weights: chosen once against a synthetic S16k-style tile so that
+# conf 0.7 leaves O(10-100) candidates per 512x512 tile ("Seeded weights")
+SEEDED_CLS_BIAS = -3.4
+_SILU_M, _SILU_Q = 0.20645, 0.35568        # E[silu(z)], E[silu(z)^2] for z ~ N(0,1)
+
+
+def _input_moments(scale, nc):
+    """Mean-square of every conv's input, propagated analytically through the graph (independence
+    assumption) so that the seeded BatchNorm statistics keep every pre-activation ~N(0,1):
+    SiLU output (m,q)=(0.206,0.356); shortcut add: m+=0.206, q+=0.356+2*m_prev*0.206; concat = channel mean."""
+    c = S.channels(scale)
+    n3, n6 = c["n3"], c["n6"]
+    q = {}
+    act = (_SILU_M, _SILU_Q)
+
+    def c2f(i, q_in, n, shortcut):
+        q["model.%d.cv1" % i] = q_in
+        m_cur, q_cur = act
+        segs = [act[1], act[1]]
+        for j in range(n):
+            q["model.%d.m.%d.cv1" % (i, j)] = q_cur
+            q["model.%d.m.%d.cv2" % (i, j)] = act[1]
+            if shortcut:
+                q_cur = q_cur + act[1] + 2 * m_cur * act[0]
+                m_cur = m_cur + act[0]
+            else:
+                m_cur, q_cur = act
+            segs.append(q_cur)
+        q["model.%d.cv2" % i] = float(np.mean(segs))
+    q["model.0"] = 0.25
+    for i in (1, 3, 5, 7, 16, 19):
+        q["model.%d" % i] = act[1]
+    c2f(2, act[1], n3, True); c2f(4, act[1], n6, True); c2f(6, act[1], n6, True); c2f(8, act[1], n3, True)
+    q["model.9.cv1"] = act[1]
+    q["model.9.cv2"] = float(np.mean([act[1], 1.2, 1.9, 2.4]))       # a, mp5(a), mp9(a), mp13(a): rough
+    for i in (12, 15, 18, 21):
+        c2f(i, act[1], n3, False)
+    for lvl in range(3):
+        for br in ("cv2", "cv3"):
+            for k in range(3):
+                q["model.22.%s.%d.%d" % (br, lvl, k)] = act[1]
+    return q
+
+
+def _variance_table(scale, nc):
+    """Per-conv variance of the raw conv output: the analytic estimate, refined by the table that
+    tests/tools/calibrate_seeded.py measured once (seeded_calibration.json, plain data)."""
+    t = _input_moments(scale, nc)
+    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "seeded_calibration.json")
+    if os.path.exists(p):
+        with open(p) as fp:
+            t.update(json.load(fp).get(scale, {}))
+    return t
+
+
+def seeded_checkpoint(scale="l", nc=5, seed=20260104, cls_bias=SEEDED_CLS_BIAS, var_table=None):
+    rng = np.random.default_rng(seed)
+    qin = var_table if var_table is not None else _variance_table(scale, nc)
+    ck = {}
+    for cs in S.conv_list(scale, nc):
+        fan_in = cs.cin * cs.k * cs.k
+        w = rng.standard_normal((cs.cout, cs.cin, cs.k, cs.k), dtype=np.float32) * np.float32(1.0 / np.sqrt(fan_in))
+        v = qin[cs.name]                      # expected variance of the raw conv output (unit-variance weights/fan_in)
+        if cs.bn:
+            ck[cs.name + ".conv.weight"] = w
+            ck[cs.name + ".bn.weight"] = rng.uniform(0.9, 1.1, cs.cout).astype(np.float32)
+            ck[cs.name + ".bn.bias"] = (rng.standard_normal(cs.cout) * 0.1).astype(np.float32)
+            ck[cs.name + ".bn.running_mean"] = (rng.standard_normal(cs.cout) * 0.1 * np.sqrt(v)).astype(np.float32)
+            ck[cs.name + ".bn.running_var"] = (rng.uniform(0.9, 1.1, cs.cout) * v).astype(np.float32)
+        else:
+            boost = 1.0 if ".cv3." in cs.name else 2.0       # wider DFL logits -> varied box sizes
+            ck[cs.name + ".weight"] = (w * np.float32(boost / np.sqrt(v))).astype(np.float32)
+            if ".cv3." in cs.name:
+                b = np.full(cs.cout, cls_bias, np.float32) + (rng.standard_normal(cs.cout) * 0.05).astype(np.float32)
+            else:                              # DFL logits biased to low bins -> boxes of a few cells
+                b = np.tile(1.0 - 0.6 * np.arange(S.REG_MAX, dtype=np.float32), 4)
+            ck[cs.name + ".bias"] = b.astype(np.float32)
+    return ck
+
+
+def fold(ck, scale="l", nc=5):
+    """-> list of (ConvSpec, W fp32 [co,ci,k,k], b fp32 [co]) in canonical order."""
+    out = []
+    for cs in S.conv_list(scale, nc):
+        if cs.bn:
+            w = ck[cs.name + ".conv.weight"].astype(np.float32)
+            g, beta = ck[cs.name + ".bn.weight"], ck[cs.name + ".bn.bias"]
+            mu, var = ck[cs.name + ".bn.running_mean"], ck[cs.name + ".bn.running_var"]
+            sc = (g / np.sqrt(var + np.float32(BN_EPS))).astype(np.float32)
+            wf = (w * sc[:, None, None, None]).astype(np.float32)
+            bf = (beta - mu * sc).astype(np.float32)
+        else:
+            wf = ck[cs.name + ".weight"].astype(np.float32)
+            bf = ck[cs.name + ".bias"].astype(np.float32)
+        assert wf.shape == (cs.cout, cs.cin, cs.k, cs.k), (cs.name, wf.shape)
+        out.append((cs, np.ascontiguousarray(wf), np.ascontiguousarray(bf)))
+    return out
+
+
+def _pad4(b):
+    return b + b"\0" * ((-len(b)) % 4)
+
+
+def write_cyw(path, folded, names, scale="l"):
+    nc = len(names)
+    with open(path, "wb") as fp:
+        fp.write(b"CYW1" + struct.pack("<I", 1) + scale.encode().ljust(4, b"\0") +
+                 struct.pack("<III", nc, len(folded), nc))
+        for i in range(nc):
+            nb = str(names[i]).encode()
+            fp.write(struct.pack("<I", len(nb)) + _pad4(nb))
+        for cs, w, b in folded:
+            nb = cs.name.encode()
+            fp.write(struct.pack("<IIIIII", cs.cout, cs.cin, cs.k, cs.s, int(cs.act), len(nb)) + _pad4(nb))
+            fp.write(w.astype("<f4").tobytes())
+            fp.write(b.astype("<f4").tobytes())
+
+
+def read_cyw(path):
+    """-> (scale, names dict, {conv name: (W, b)}, [(name,cout,cin,k,s,act)] in file order)."""
+    with open(path, "rb") as fp:
+        buf = fp.read()
+    if buf[:4] != b"CYW1":
+        raise ValueError("%s: not a CYW1 weight file" % path)
+    ver, = struct.unpack_from("<I", buf, 4)
+    if ver != 1:
+        raise ValueError("unsupported CYW version %d" % ver)
+    scale = buf[8:12].rstrip(b"\0").decode()
+    nc, nconv, nnames = struct.unpack_from("<III", buf, 12)
+    off = 24
+    names = {}
+    for i in range(nnames):
+        n, = struct.unpack_from("<I", buf, off)
+        off += 4
+        names[i] = buf[off:off + n].decode()
+        off += (n + 3) // 4 * 4
+    w, order = {}, []
+    for _ in range(nconv):
+        co, ci, k, s, act, n = struct.unpack_from("<IIIIII", buf, off)
+        off += 24
+        name = buf[off:off + n].decode()
+        off += (n + 3) // 4 * 4
+        cnt = co * ci * k * k
+        W = np.frombuffer(buf, "<f4", cnt, off).reshape(co, ci, k, k)
+        off += 4 * cnt
+        b = np.frombuffer(buf, "<f4", co, off)
+        off += 4 * co
+        w[name] = (W, b)
+        order.append((name, co, ci, k, s, act))
+    return scale, names, w, order
+
+
+def make_seeded_file(path, scale="l", nc=5, seed=20260104, names=None):
+    names = names or {i: S.DEFAULT_NAMES.get(i, "class%d" % i) for i in range(nc)}
+    ck = seeded_checkpoint(scale, nc, seed)
+    write_cyw(path, fold(ck, scale, nc), names, scale)
+    return path
