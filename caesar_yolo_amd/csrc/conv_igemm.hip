@@ -1,0 +1,409 @@
+// Fused Conv2d + folded-BN bias + SiLU (+ residual, + concat/upsample gather, + channel-slice store) as an
+// implicit GEMM on CDNA4 matrix cores (gfx950 only).
+//
+// Replaces ultralytics `Conv.forward_fuse` / `Bottleneck` / `Concat` / `nn.Upsample` as executed inside the
+// reference's model call (caesar_yolo/evaluation.py:181-193; graph: SURVEY.md Appendix A.1 step 4, Appendix B).
+//
+// GEMM view (per launch): D[n, m] = sum_k W[n, k] * X[m, k]
+//   m = output pixel (b, ho, wo) over the whole tile batch, n = output channel, k = (tap, input channel).
+//   The weights are the MFMA "A" operand and the im2col rows the "B" operand, so an accumulator lane holds
+//   FOUR CONSECUTIVE CHANNELS of ONE pixel: with the 64-row weight permutation done at pack time a lane owns 16
+//   contiguous channels of a pixel and the NHWC store is 16-byte vectors (no LDS transpose in the epilogue).
+//   f16: v_mfma_f32_16x16x32_f16 (fp32 accumulate).  f32 (parity mode): v_mfma_f32_16x16x4_f32 = exact fp32 FMA chain.
+//
+// Data movement: K is walked in 128-byte slabs per row (64 halves / 32 floats of one filter tap).  Each thread
+// fetches 16-byte pieces with buffer loads whose hardware range check supplies the zero padding of the 3x3 halo
+// and of ragged channel counts (an out-of-range offset reads 0), stages them in registers while the previous slab
+// is on the matrix pipe, and writes them to a double-buffered, XOR-swizzled LDS image that ds_read_b128 reads
+// conflict-free (slot = chunk ^ ((row>>1)&7); a 256-byte bank row holds two 128-byte tile rows).
+#include "cy_kernels.h"
+
+namespace cy {
+
+typedef _Float16 f16;
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+#define CY_OOB 0xFFFFFF00u
+
+__device__ __forceinline__ float silu_exact(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float silu_fast(float x) { return x * __frcp_rn(1.0f + __expf(-x)); }
+
+template <typename T> struct Elem;
+template <> struct Elem<f16> { static constexpr int BKE = 64, EPC = 8, ES = 2; };
+template <> struct Elem<float> { static constexpr int BKE = 32, EPC = 4, ES = 4; };
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous run of tiles so that
+    // neighbouring tiles (same activation rows, different channel blocks) hit one L2.  Bijective for any nwg.
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+template <typename T, int WM, int WN, int MI>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
+    constexpr int BM = WM * MI * 16, BN = WN * 64;
+    constexpr int BKE = Elem<T>::BKE, EPC = Elem<T>::EPC, ES = Elem<T>::ES;
+    constexpr int AROWS = BM / 32, BROWS = BN / 32;          // rows each thread stages per slab
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int M = a.B * a.Ho * a.Wo;
+    const int ntn = (pad64(a.Cout) + BN - 1) / BN;
+    const int nwg = gridDim.x;
+    const int id = xcd_remap(blockIdx.x, nwg);
+    const int m0 = (id / ntn) * BM, n0 = (id % ntn) * BN;
+    const int taps = a.k * a.k;
+    const int cchunks = (a.Cin + BKE - 1) / BKE;
+    const int nslab = taps * cchunks;
+
+    const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in0), 0, a.in0_bytes, 0x00020000);
+    const auto rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.c1 ? a.in1 : a.in0), 0,
+                                                       a.c1 ? a.in1_bytes : a.in0_bytes, 0x00020000);
+    const auto rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wgt), 0, a.wgt_bytes, 0x00020000);
+
+    // ---- per-thread staging geometry: chunk q of rows (tid>>3) + 32*i
+    const int q = tid & 7, r0 = tid >> 3;
+    int pix0[AROWS], pix1[AROWS];
+    unsigned vmask[AROWS];
+    const int pad = a.k >> 1;
+    const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        unsigned vm = 0;
+        int p0 = 0, p1 = 0;
+        if (m < M) {
+            const int b = m / HoWo, r = m - b * HoWo;
+            const int ho = r / a.Wo, wo = r - ho * a.Wo;
+            const int hi0 = ho * a.s - pad, wi0 = wo * a.s - pad;
+            for (int kh = 0; kh < a.k; ++kh)
+                for (int kw = 0; kw < a.k; ++kw)
+                    if ((unsigned)(hi0 + kh) < (unsigned)a.Hi && (unsigned)(wi0 + kw) < (unsigned)a.Wi)
+                        vm |= 1u << (kh * a.k + kw);
+            if (a.up0) p0 = (b * (a.Hi >> 1) + (ho >> 1)) * (a.Wi >> 1) + (wo >> 1);
+            else p0 = (b * a.Hi + hi0) * a.Wi + wi0;
+            p1 = (b * a.Hi + hi0) * a.Wi + wi0;
+        }
+        pix0[i] = p0; pix1[i] = p1; vmask[i] = vm;
+    }
+
+    u32x4 ra[AROWS], rb[BROWS];
+    auto fetch = [&](int tap, int cc) {
+        const int c = cc * BKE + q * EPC;
+        const int kh = tap / a.k, kw = tap - kh * a.k;
+        const int dpix = kh * a.Wi + kw;
+        const bool cin_ok = c < a.Cin;
+        const bool seg1 = c >= a.c0;
+#pragma unroll
+        for (int i = 0; i < AROWS; ++i) {
+            const bool ok = cin_ok && ((vmask[i] >> tap) & 1u);
+            unsigned off;
+            if (!seg1) off = (unsigned)((pix0[i] + (a.up0 ? 0 : dpix)) * a.in0_ct + a.in0_coff + c) * ES;
+            else       off = (unsigned)((pix1[i] + dpix) * a.in1_ct + a.in1_coff + (c - a.c0)) * ES;
+            off = ok ? off : CY_OOB;
+            ra[i] = seg1 ? __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 0, 0)
+                         : __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < BROWS; ++i) {
+            const int n = n0 + r0 + 32 * i;
+            unsigned off = (unsigned)((n * taps + tap) * a.Cin + c) * ES;
+            off = cin_ok ? off : CY_OOB;
+            rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsw, off, 0, 0);
+        }
+    };
+    auto stash = [&](int stage) {
+        char* A = smem + stage * STAGE;
+        char* Bm = A + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < AROWS; ++i) {
+            const int r = r0 + 32 * i;
+            *reinterpret_cast<u32x4*>(A + r * 128 + ((q ^ ((r >> 1) & 7)) << 4)) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < BROWS; ++i) {
+            const int r = r0 + 32 * i;
+            *reinterpret_cast<u32x4*>(Bm + r * 128 + ((q ^ ((r >> 1) & 7)) << 4)) = rb[i];
+        }
+    };
+
+    f32x4 acc[4][MI];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fq = lane >> 4;
+    auto compute = [&](int stage) {
+        const char* A = smem + stage * STAGE;
+        const char* Bm = A + A_BYTES;
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int qf = fq + 4 * kk;
+                f16x8 xa[MI], wb[4];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const int r = wm * (MI * 16) + mi * 16 + fr;
+                    xa[mi] = *reinterpret_cast<const f16x8*>(A + r * 128 + ((qf ^ ((r >> 1) & 7)) << 4));
+                }
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const int r = wn * 64 + ni * 16 + fr;
+                    wb[ni] = *reinterpret_cast<const f16x8*>(Bm + r * 128 + ((qf ^ ((r >> 1) & 7)) << 4));
+                }
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                float xa[MI], wb[4];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const int r = wm * (MI * 16) + mi * 16 + fr;
+                    xa[mi] = *reinterpret_cast<const float*>(A + r * 128 + ((ks ^ ((r >> 1) & 7)) << 4) + fq * 4);
+                }
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const int r = wn * 64 + ni * 16 + fr;
+                    wb[ni] = *reinterpret_cast<const float*>(Bm + r * 128 + ((ks ^ ((r >> 1) & 7)) << 4) + fq * 4);
+                }
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- main loop: one barrier per slab; global loads for slab s+1 are in flight while slab s is on the MFMA pipe
+    int tap = 0, cc = 0;
+    fetch(0, 0);
+    stash(0);
+    __syncthreads();
+    for (int s = 0; s < nslab; ++s) {
+        int ntap = tap, ncc = cc + 1;
+        if (ncc == cchunks) { ncc = 0; ++ntap; }
+        const bool more = (s + 1) < nslab;
+        if (more) fetch(ntap, ncc);
+        compute(s & 1);
+        if (more) stash((s + 1) & 1);
+        __syncthreads();
+        tap = ntap; cc = ncc;
+    }
+
+    // ---- epilogue: bias + SiLU (+ residual) and 16 contiguous channels per lane per pixel
+    const int cbase = n0 + wn * 64 + fq * 16;
+    float bv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) bv[j] = a.bias[cbase + j];       // bias is padded to Cout_pad64
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = m0 + wm * (MI * 16) + mi * 16 + fr;
+        if (m >= M) continue;
+        const int b = m / HoWo, r = m - b * HoWo;
+        const long opix = (long)b * a.out_bs + a.out_ro + r;
+        float v[16];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float x = acc[ni][mi][j] + bv[ni * 4 + j];
+                if (a.act) x = (sizeof(T) == 2) ? silu_fast(x) : silu_exact(x);
+                v[ni * 4 + j] = x;
+            }
+        const bool full = (cbase + 16 <= a.Cout) && !a.out_f32;
+        if (full) {
+            T* dst = reinterpret_cast<T*>(a.out) + opix * a.out_ct + a.out_coff + cbase;
+            if (a.res) {
+                const T* rp = reinterpret_cast<const T*>(a.res) + (long)m * a.res_ct + a.res_coff + cbase;
+                if constexpr (sizeof(T) == 2) {
+                    const f16x8 r0v = *reinterpret_cast<const f16x8*>(rp), r1v = *reinterpret_cast<const f16x8*>(rp + 8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { v[j] += (float)r0v[j]; v[8 + j] += (float)r1v[j]; }
+                } else {
+#pragma unroll
+                    for (int j4 = 0; j4 < 4; ++j4) {
+                        const f32x4 rv = *reinterpret_cast<const f32x4*>(rp + 4 * j4);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[4 * j4 + j] += rv[j];
+                    }
+                }
+            }
+            if constexpr (sizeof(T) == 2) {
+                f16x8 o0, o1;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { o0[j] = (f16)v[j]; o1[j] = (f16)v[8 + j]; }
+                *reinterpret_cast<f16x8*>(dst) = o0;
+                *reinterpret_cast<f16x8*>(dst + 8) = o1;
+            } else {
+#pragma unroll
+                for (int j4 = 0; j4 < 4; ++j4)
+                    *reinterpret_cast<f32x4*>(dst + 4 * j4) = f32x4{v[4 * j4], v[4 * j4 + 1], v[4 * j4 + 2], v[4 * j4 + 3]};
+            }
+        } else {
+            // ragged channel count or fp32 head output: scalar stores (detect-head 1x1 convs only)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int c = cbase + j;
+                if (c >= a.Cout) continue;
+                float x = v[j];
+                if (a.res) x += (float)(reinterpret_cast<const T*>(a.res)[(long)m * a.res_ct + a.res_coff + c]);
+                if (a.out_f32) reinterpret_cast<float*>(a.out)[opix * a.out_ct + a.out_coff + c] = x;
+                else reinterpret_cast<T*>(a.out)[opix * a.out_ct + a.out_coff + c] = (T)x;
+            }
+        }
+    }
+}
+
+template <typename T, int WM, int WN, int MI>
+static hipError_t launch_t(const ConvArgs& a, hipStream_t s) {
+    constexpr int BM = WM * MI * 16, BN = WN * 64;
+    const int M = a.B * a.Ho * a.Wo;
+    const int ntm = (M + BM - 1) / BM, ntn = (pad64(a.Cout) + BN - 1) / BN;
+    const size_t lds = 2 * (BM + BN) * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, WM, WN, MI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, MI>), dim3(ntm * ntn), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s) {
+    const bool narrow = pad64(a.Cout) <= 64;
+    if (p == PREC_F16) return narrow ? launch_t<f16, 4, 1, 2>(a, s) : launch_t<f16, 2, 2, 4>(a, s);
+    return narrow ? launch_t<float, 4, 1, 2>(a, s) : launch_t<float, 2, 2, 4>(a, s);
+}
+
+// ------------------------------------------------------------------------------------------------ weights
+size_t packed_weight_bytes(Precision p, int cout, int cin, int k) {
+    return (size_t)pad64(cout) * k * k * cin * (p == PREC_F16 ? 2 : 4);
+}
+
+void pack_weights(Precision p, const float* W, int cout, int cin, int k, void* dst) {
+    const int taps = k * k, cp = pad64(cout);
+    for (int row = 0; row < cp; ++row) {
+        const int blk = row >> 6, ni = (row >> 4) & 3, rr = row & 15;
+        const int n = blk * 64 + (rr >> 2) * 16 + ni * 4 + (rr & 3);      // channel held by packed row `row`
+        for (int t = 0; t < taps; ++t)
+            for (int c = 0; c < cin; ++c) {
+                const float v = n < cout ? W[((size_t)n * cin + c) * taps + t] : 0.0f;
+                const size_t o = ((size_t)row * taps + t) * cin + c;
+                if (p == PREC_F16) reinterpret_cast<f16*>(dst)[o] = (f16)v;
+                else reinterpret_cast<float*>(dst)[o] = v;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ stem
+// Layer 0: Conv(3, C, 3, 2) on the NHWC4 network input.  K = 27 is too small for the matrix cores to matter; the
+// layer is bound by its 64-channel output write.  One thread = one output pixel x 16 output channels.
+template <typename T>
+__global__ __launch_bounds__(256) void stem_kernel(const StemArgs a) {
+    __shared__ float w[27 * 64];
+    __shared__ float bs[64];
+    const int co_blocks = a.Cout / 16;
+    for (int i = threadIdx.x; i < 27 * a.Cout; i += 256) w[i] = a.w[i];
+    for (int i = threadIdx.x; i < a.Cout; i += 256) bs[i] = a.bias[i];
+    __syncthreads();
+    const long total = (long)a.B * a.Ho * a.Wo * co_blocks;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int cb = (int)(idx % co_blocks);
+        const long pix = idx / co_blocks;
+        const int wo = (int)(pix % a.Wo);
+        const int ho = (int)((pix / a.Wo) % a.Ho);
+        const int b = (int)(pix / ((long)a.Wo * a.Ho));
+        float x[27];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int hi = ho * 2 - 1 + kh, wi = wo * 2 - 1 + kw;
+                const bool ok = (unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi;
+                typedef T vec4 __attribute__((ext_vector_type(4)));
+                vec4 pv = {(T)0, (T)0, (T)0, (T)0};
+                if (ok) pv = *reinterpret_cast<const vec4*>(reinterpret_cast<const T*>(a.in) +
+                                                            (((long)b * a.Hi + hi) * a.Wi + wi) * 4);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) x[(kh * 3 + kw) * 3 + c] = (float)pv[c];
+            }
+        float acc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 27; ++t)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = fmaf(x[t], w[t * a.Cout + cb * 16 + j], acc[j]);
+        T* dst = reinterpret_cast<T*>(a.out) + pix * a.out_ct + a.out_coff + cb * 16;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float v = acc[j] + bs[cb * 16 + j];
+            dst[j] = (T)((sizeof(T) == 2) ? silu_fast(v) : silu_exact(v));
+        }
+    }
+}
+
+hipError_t launch_stem(Precision p, const StemArgs& a, hipStream_t s) {
+    if (a.Cout > 64 || a.Cout % 16) return hipErrorInvalidValue;
+    const long total = (long)a.B * a.Ho * a.Wo * (a.Cout / 16);
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (p == PREC_F16) hipLaunchKernelGGL(stem_kernel<f16>, dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(stem_kernel<float>, dim3(grid), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ SPPF pool
+// MaxPool2d(kernel 5, stride 1, padding 2) with implicit -inf padding, slice -> slice of one NHWC buffer.
+template <typename T>
+__global__ __launch_bounds__(256) void pool5_kernel(const PoolArgs a) {
+    constexpr int V = 16 / sizeof(T);
+    typedef T vec __attribute__((ext_vector_type(V)));
+    const int cv = a.C / V;
+    const long total = (long)a.B * a.H * a.W * cv;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % cv) * V;
+        const long pix = idx / cv;
+        const int w = (int)(pix % a.W), h = (int)((pix / a.W) % a.H), b = (int)(pix / ((long)a.W * a.H));
+        vec m;
+        bool first = true;
+        for (int dh = -2; dh <= 2; ++dh)
+            for (int dw = -2; dw <= 2; ++dw) {
+                const int hh = h + dh, ww = w + dw;
+                if ((unsigned)hh >= (unsigned)a.H || (unsigned)ww >= (unsigned)a.W) continue;
+                const vec v = *reinterpret_cast<const vec*>(reinterpret_cast<const T*>(a.src) +
+                                                            (((long)b * a.H + hh) * a.W + ww) * a.ct + a.src_coff + c);
+                if (first) { m = v; first = false; }
+                else {
+#pragma unroll
+                    for (int j = 0; j < V; ++j) m[j] = v[j] > m[j] ? v[j] : m[j];
+                }
+            }
+        *reinterpret_cast<vec*>(reinterpret_cast<T*>(a.dst) + pix * a.ct + a.dst_coff + c) = m;
+    }
+}
+
+hipError_t launch_pool5(Precision p, const PoolArgs& a, hipStream_t s) {
+    const int V = p == PREC_F16 ? 8 : 4;
+    if (a.C % V) return hipErrorInvalidValue;
+    const long total = (long)a.B * a.H * a.W * (a.C / V);
+    const int grid = (int)((total + 255) / 256);
+    if (p == PREC_F16) hipLaunchKernelGGL(pool5_kernel<f16>, dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(pool5_kernel<float>, dim3(grid), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace cy

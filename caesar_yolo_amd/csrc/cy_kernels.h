@@ -1,0 +1,107 @@
+// Internal launch interfaces between the runtime (cy_context.cpp) and the gfx950 kernels.
+// Nothing here is part of the C-ABI (see include/caesar_yolo_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cy {
+
+enum Precision { PREC_F16 = 0, PREC_F32 = 1 };
+
+// One fused Conv2d(+folded BN bias)(+SiLU)(+residual) over NHWC activations, as an implicit GEMM:
+//   out[pix, n] = act( sum_{tap,c} in[pix(tap), c] * w[n, tap, c] + bias[n] ) (+ res[pix, n])
+// Input may be the channel-concat of two NHWC segments (k == 1 only); segment 0 may be read through a
+// nearest x2 upsample (nn.Upsample + Concat of yolov8 layers 10-11 / 13-14 folded into the consumer).
+struct ConvArgs {
+    const void* in0; int in0_ct, in0_coff, c0, up0;   // segment 0: base, channels per pixel of the buffer, channel offset, #channels
+    const void* in1; int in1_ct, in1_coff, c1;        // segment 1 (c1 == 0: absent)
+    const void* wgt;                                   // packed [Cout_pad64][k*k][Cin]; rows permuted per 64 (pack_weights)
+    const float* bias;                                 // [Cout_pad64]
+    void* out; int out_ct, out_coff;                   // NHWC destination slice
+    int out_bs, out_ro;                                // destination pixel = b*out_bs + out_ro + (ho*Wo+wo)
+    int out_f32;                                       // 1: store fp32 regardless of the activation type (detect head)
+    const void* res; int res_ct, res_coff;             // residual source (same pixel grid) or null
+    int B, Hi, Wi, Ho, Wo, Cin, Cout, k, s, act;
+    uint32_t in0_bytes, in1_bytes, wgt_bytes;          // buffer extents for the hardware range check
+};
+
+// First layer (Cin = 3 stored as 4, k=3, s=2): direct convolution.
+struct StemArgs {
+    const void* in; void* out; const float* w; const float* bias;   // w: [27][Cout] fp32 (tap-major, then c)
+    int B, Hi, Wi, Ho, Wo, Cout, out_ct, out_coff;
+};
+
+struct PoolArgs {   // MaxPool2d(5,1,2) on a channel slice of an NHWC buffer, -inf padding
+    const void* src; void* dst; int ct, src_coff, dst_coff, C, B, H, W;
+};
+
+hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s);
+hipError_t launch_stem(Precision p, const StemArgs& a, hipStream_t s);
+hipError_t launch_pool5(Precision p, const PoolArgs& a, hipStream_t s);
+
+// Host-side weight packing into the layout launch_conv expects.
+//   W: [Cout][Cin][k][k] fp32 -> dst: [Cout_pad64][k*k][Cin] (fp16 or fp32), rows permuted within each 64-row group
+//   so that MFMA row (ni, rr) holds channel 64*blk + 16*(rr>>2) + 4*ni + (rr&3).
+size_t packed_weight_bytes(Precision p, int cout, int cin, int k);
+void pack_weights(Precision p, const float* W, int cout, int cin, int k, void* dst);
+__host__ __device__ inline int pad64(int c) { return (c + 63) / 64 * 64; }
+
+// ---- detection post-processing --------------------------------------------------------------
+struct DecodeArgs {
+    const float* pred;       // [B][A][64+nc] raw head output (box logits, class logits)
+    int B, A, nc;
+    int lvl_h[3], lvl_w[3];  // grid of each stride-8/16/32 level
+    float conf;
+    // outputs: candidates per tile (fixed capacity cap), in anchor order
+    float* cand;             // [B][cap][6]  x1,y1,x2,y2 (letterboxed px), score, class
+    int* cand_anchor;        // [B][cap]
+    int* cand_count;         // [B] (may exceed cap; clamped by consumers)
+    int cap;
+};
+hipError_t launch_decode(const DecodeArgs& a, hipStream_t s);
+
+struct NmsArgs {
+    const float* cand; const int* cand_anchor; const int* cand_count; int cap;   // from decode
+    int B; float iou; int max_det;
+    // letterbox undo (ultralytics scale_boxes): x = (x - padw)/gain, clamp to [0,w0]x[0,h0]
+    float gain; int padw, padh, w0, h0;
+    float* det;              // [B][max_det][6]
+    int* det_anchor;         // [B][max_det] anchor index of each kept detection (parity witness)
+    int* det_count;          // [B]
+    // workspace
+    uint64_t* keys;          // [B][cap_pow2]
+    uint64_t* mask;          // [B][cap][cap/64]
+};
+hipError_t launch_nms(const NmsArgs& a, hipStream_t s);
+
+struct MergeArgs {          // Analyzer.process_detections on device
+    const float* det; const int* det_count; int B, max_det;
+    float score_thr; double soft, hard;
+    float* out; int* out_count; int* out_src;    // [B][max_det][6], [B], [B][max_det] (index into det rows)
+    int* err;               // [B] number of degenerate boxes dropped (reference would assert)
+};
+hipError_t launch_iou_merge(const MergeArgs& a, hipStream_t s);
+
+// ---- preprocessing ---------------------------------------------------------------------------
+enum PreOp { OP_BKG = 1, OP_SHIFT = 2, OP_CLIP = 3, OP_ZSCALE = 4, OP_HISTEQ = 5, OP_MINMAX = 6 };
+struct PreStage { int op; double p0, p1, p2; int flag; };   // op parameters (see cy_preproc.hip)
+constexpr int MAX_STAGES = 8;
+struct PreProgram { int n; PreStage st[MAX_STAGES]; };
+struct PreArgs {
+    const float* mosaic; int MH, MW;      // resident mosaic, native-endian fp32, non-finite already 0
+    const int* tiles;                      // [B][4] x0,y0,w,h (device)
+    int B, th, tw;                         // tile box of this shape class
+    PreProgram prog[3]; int nprog;         // 1: one program broadcast to 3 channels; 3: per-channel programs
+    double* params;                        // [B][3][MAX_STAGES][4] solved stage parameters (workspace / witness)
+    double* histeq;                        // [B][3][520] bin centres [0:256] + cdf [256:512] for OP_HISTEQ (workspace)
+    int* status;                           // [B] 0 ok, 1 preprocessing returned None, 2 constant-row check failed
+    // network input
+    void* out; int out_prec; int H, W, top, left;   // NHWC4 letterboxed canvas, fill 114/255
+    double* scratch;                       // [B][3][th*tw] fp64 preprocessed image when a resize is needed, else null
+    int new_h, new_w;                      // resized size (== th,tw when no resize)
+};
+hipError_t launch_preproc(const PreArgs& a, hipStream_t s);
+hipError_t launch_letterbox_pack(const PreArgs& a, hipStream_t s);   // uses scratch/th/tw/new_*/H/W/top/left/out only
+hipError_t launch_mosaic_prepare(float* data, size_t n, int big_endian, hipStream_t s);
+
+}  // namespace cy

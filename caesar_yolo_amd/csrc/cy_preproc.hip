@@ -1,0 +1,572 @@
+// Per-tile preprocessing on device (gfx950): tiles never leave HBM.
+//
+// Replaces, for B same-shape tiles cropped from the resident mosaic:
+//   utils.read_fits_crop value semantics   caesar_yolo/utils.py:373-394 (non-finite -> 0; big-endian FITS floats)
+//   Analyzer.predict                        caesar_yolo/evaluation.py:146-176 (3-channel float64 cube, pipeline, None and
+//                                           constant-row rejection)
+//   DataPreprocessor + CLI-reachable stages caesar_yolo/preprocessing.py: BkgSubtractor :591-658, SigmaClipShifter :664-717,
+//                                           SigmaClipper :723-771, ZScaleTransformer :934-971, HistEqualizer :977-1012,
+//                                           Chan3Trasformer :1020-1072, MinMaxNormalizer :75-111
+//   astropy ZScaleInterval / sigma_clip / sigma_clipped_stats and skimage equalize_hist as restated in SURVEY.md A.2-A.4
+//   ultralytics LetterBox + channel flip + /255
+//
+// Every stage is "global statistics of the stage input, then a per-pixel map, then zero where the stage input was 0 or
+// non-finite".  The statistics kernel therefore never materialises intermediate images: a stage's input pixel is
+// recomputed from the raw fp32 pixel by replaying the already-solved maps in float64, operation for operation as numpy
+// does (contraction off), so thresholds see bit-identical values.  One 1024-thread workgroup owns one (tile, channel
+// program) and walks its stages; medians are exact (64-bit radix select, even counts average the two middle values).
+#include "cy_kernels.h"
+#include <math.h>
+#pragma clang fp contract(off)
+
+namespace cy {
+
+constexpr int NT = 1024;            // threads per statistics workgroup
+constexpr int PSTRIDE = MAX_STAGES * 4;
+constexpr int HEQ_STRIDE = 520;     // 256 centres + 256 cdf (+pad) doubles per (tile, channel)
+
+__device__ __forceinline__ bool cond_of(double v) { return v != 0.0 && isfinite(v); }
+
+__device__ __forceinline__ double interp256(double x, const double* xp, const double* fp) {
+    // numpy.interp for 256 knots (compiled_base.c arr_interp): left/right clamps, exact knot hits, slope form
+    if (x > xp[255]) return fp[255];
+    if (x < xp[0]) return fp[0];
+    int lo = 0, hi = 255;                       // largest j with xp[j] <= x
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (xp[mid] <= x) lo = mid; else hi = mid; }
+    int j = (xp[hi] <= x) ? hi : lo;
+    if (j == 255) return fp[255];
+    if (xp[j] == x) return fp[j];
+    const double slope = (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j]);
+    return slope * (x - xp[j]) + fp[j];
+}
+
+// stage k applied to its input value v, with solved parameters sp[4]
+__device__ __forceinline__ double apply_stage(const PreStage& st, const double* sp, const double* heq, double v) {
+    const bool c = cond_of(v);
+    double o = v;
+    switch (st.op) {
+        case OP_BKG: o = v - sp[0]; break;
+        case OP_SHIFT: o = v - sp[0]; if (o < 0.0) o = 0.0; break;
+        case OP_CLIP: if (o < sp[0]) o = sp[0]; if (o > sp[1]) o = sp[1]; break;
+        case OP_ZSCALE: {
+            o = v - sp[0];
+            const double rng = sp[1] - sp[0];
+            if (rng != 0.0) o = o / rng;
+            o = fmin(fmax(o, 0.0), 1.0);
+            break;
+        }
+        case OP_HISTEQ: o = interp256(v, heq, heq + 256); break;
+        case OP_MINMAX: o = (v - sp[0]) / (sp[1] - sp[0]) * (st.p1 - st.p0) + st.p0; break;
+        default: break;
+    }
+    return c ? o : 0.0;
+}
+
+__device__ __forceinline__ double chain_value(const PreProgram& pg, int upto, const double* params, const double* heq, double raw) {
+    double v = raw;
+    for (int k = 0; k < upto; ++k) v = apply_stage(pg.st[k], params + k * 4, heq, v);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------- block primitives
+struct Smem {
+    double red[32];
+    unsigned hist[2048];
+    unsigned scan[NT];
+    double zs[1024];
+    unsigned char bad[1024], bad2[1024];
+    double bc[8];
+    unsigned long long bcu[4];
+    int bci[4];
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_down(v, o));
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o));
+    return v;
+}
+// all threads get the result; fixed tree => run-to-run deterministic
+template <int MODE> __device__ double block_reduce(Smem& s, double v) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    v = MODE == 0 ? wave_sum(v) : (MODE == 1 ? wave_min(v) : wave_max(v));
+    __syncthreads();
+    if (lane == 0) s.red[w] = v;
+    __syncthreads();
+    if (w == 0) {
+        double x = lane < NT / 64 ? s.red[lane] : (MODE == 0 ? 0.0 : (MODE == 1 ? INFINITY : -INFINITY));
+        x = MODE == 0 ? wave_sum(x) : (MODE == 1 ? wave_min(x) : wave_max(x));
+        if (lane == 0) s.red[0] = x;
+    }
+    __syncthreads();
+    const double r = s.red[0];
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ double block_sum(Smem& s, double v) { return block_reduce<0>(s, v); }
+__device__ __forceinline__ double block_min(Smem& s, double v) { return block_reduce<1>(s, v); }
+__device__ __forceinline__ double block_max(Smem& s, double v) { return block_reduce<2>(s, v); }
+
+__device__ __forceinline__ unsigned long long dkey(double v) {          // order-preserving double -> u64
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double dkey_inv(unsigned long long k) {
+    const unsigned long long b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+
+struct TileView {
+    const float* base; int MW, tw, th, npix;
+    __device__ __forceinline__ double raw(int i) const { const int y = i / tw, x = i - y * tw; return (double)base[(size_t)y * MW + x]; }
+};
+
+// membership of pixel value v in the current sigma-clip set
+struct ClipSet { double L, U; int use_box, bx0, bx1, by0, by1; };
+__device__ __forceinline__ bool in_set(const ClipSet& cs, const TileView& tv, int i, double v) {
+    if (!cond_of(v)) return false;
+    if (cs.use_box) { const int y = i / tv.tw, x = i - y * tv.tw; if (y >= cs.by0 && y < cs.by1 && x >= cs.bx0 && x < cs.bx1) return false; }
+    return v >= cs.L && v <= cs.U;
+}
+
+// exact k-th smallest (0-based) of the set, as a key; 6 passes of 11/11/11/11/11/9 bits
+__device__ unsigned long long radix_select(Smem& s, const TileView& tv, const PreProgram& pg, int upto, const double* params,
+                                           const double* heq, const ClipSet& cs, unsigned long long k) {
+    unsigned long long prefix = 0ull, pmask = 0ull;
+    const int shifts[6] = {53, 42, 31, 20, 9, 0};
+    const int bits[6] = {11, 11, 11, 11, 11, 9};
+    for (int p = 0; p < 6; ++p) {
+        const int nb = 1 << bits[p];
+        for (int i = threadIdx.x; i < nb; i += NT) s.hist[i] = 0u;
+        __syncthreads();
+        for (int i = threadIdx.x; i < tv.npix; i += NT) {
+            const double v = chain_value(pg, upto, params, heq, tv.raw(i));
+            if (!in_set(cs, tv, i, v)) continue;
+            const unsigned long long key = dkey(v);
+            if ((key & pmask) != prefix) continue;
+            atomicAdd(&s.hist[(unsigned)((key >> shifts[p]) & (unsigned long long)(nb - 1))], 1u);
+        }
+        __syncthreads();
+        // locate the bucket holding rank k: thread t owns bins 2t, 2t+1; exclusive scan of the pair sums
+        const int t = threadIdx.x;
+        const unsigned h0 = (2 * t < nb) ? s.hist[2 * t] : 0u, h1 = (2 * t + 1 < nb) ? s.hist[2 * t + 1] : 0u;
+        s.scan[t] = h0 + h1;
+        __syncthreads();
+        for (int off = 1; off < NT; off <<= 1) {
+            const unsigned add = t >= off ? s.scan[t - off] : 0u;
+            __syncthreads();
+            s.scan[t] += add;
+            __syncthreads();
+        }
+        const unsigned long long incl = s.scan[t], excl = incl - (h0 + h1);
+        if (k >= excl && k < incl) {
+            int bin; unsigned long long before;
+            if (k < excl + h0) { bin = 2 * t; before = excl; } else { bin = 2 * t + 1; before = excl + h0; }
+            s.bcu[0] = (unsigned long long)bin; s.bcu[1] = before;
+        }
+        __syncthreads();
+        prefix |= s.bcu[0] << shifts[p];
+        pmask |= (unsigned long long)(nb - 1) << shifts[p];
+        k -= s.bcu[1];
+        __syncthreads();
+    }
+    return prefix;
+}
+
+struct ClipStats { double lo, hi, mean, median, std; unsigned long long n; };
+
+__device__ double set_median(Smem& s, const TileView& tv, const PreProgram& pg, int upto, const double* params, const double* heq,
+                             const ClipSet& cs, unsigned long long n) {
+    const unsigned long long k1 = (n - 1) / 2;
+    const unsigned long long ka = radix_select(s, tv, pg, upto, params, heq, cs, k1);
+    const double a = dkey_inv(ka);
+    if (n & 1ull) return a;
+    // even count: the upper middle is `a` again if duplicates cover rank n/2, else the smallest value above `a`
+    double cle = 0.0, nxt = INFINITY;
+    for (int i = threadIdx.x; i < tv.npix; i += NT) {
+        const double v = chain_value(pg, upto, params, heq, tv.raw(i));
+        if (!in_set(cs, tv, i, v)) continue;
+        if (v <= a) cle += 1.0; else nxt = fmin(nxt, v);
+    }
+    cle = block_sum(s, cle);
+    nxt = block_min(s, nxt);
+    const double b = (cle >= (double)(n / 2 + 1)) ? a : nxt;
+    return 0.5 * (a + b);
+}
+
+// astropy SigmaClip._sigmaclip_noaxis (maxiters 5, median centre, std spread) + statistics of the survivors
+__device__ ClipStats sigma_clip_run(Smem& s, const TileView& tv, const PreProgram& pg, int upto, const double* params, const double* heq,
+                                    double slo, double sup, int use_box, double mask_fract) {
+    ClipSet cs{-INFINITY, INFINITY, use_box, 0, 0, 0, 0};
+    if (use_box) {
+        const int xc = tv.tw / 2, yc = tv.th / 2;
+        const int dy = (int)(tv.th * mask_fract / 2.0), dx = (int)(tv.tw * mask_fract / 2.0);
+        cs.bx0 = xc - dx; cs.bx1 = xc + dx; cs.by0 = yc - dy; cs.by1 = yc + dy;
+        if (cs.bx0 < 0) cs.bx0 = 0;          // numpy slice clamps (negative starts cannot occur for fract <= 1)
+        if (cs.by0 < 0) cs.by0 = 0;
+    }
+    ClipStats r{NAN, NAN, NAN, NAN, NAN, 0ull};
+    double cnt = 0.0, sum = 0.0;
+    for (int i = threadIdx.x; i < tv.npix; i += NT) {
+        const double v = chain_value(pg, upto, params, heq, tv.raw(i));
+        if (in_set(cs, tv, i, v)) { cnt += 1.0; sum += v; }
+    }
+    cnt = block_sum(s, cnt); sum = block_sum(s, sum);
+    unsigned long long n = (unsigned long long)cnt;
+    bool fresh = false;                      // are mean/median/std valid for the CURRENT set?
+    for (int it = 0; it < 5 && n > 0; ++it) {
+        const double mean = sum / (double)n;
+        double ssq = 0.0;
+        for (int i = threadIdx.x; i < tv.npix; i += NT) {
+            const double v = chain_value(pg, upto, params, heq, tv.raw(i));
+            if (in_set(cs, tv, i, v)) { const double d = v - mean; ssq += d * d; }
+        }
+        ssq = block_sum(s, ssq);
+        const double sd = sqrt(ssq / (double)n);
+        const double med = set_median(s, tv, pg, upto, params, heq, cs, n);
+        r.mean = mean; r.median = med; r.std = sd; r.n = n;
+        r.lo = med - sd * slo; r.hi = med + sd * sup;
+        cs.L = fmax(cs.L, r.lo); cs.U = fmin(cs.U, r.hi);
+        double c2 = 0.0, s2 = 0.0;
+        for (int i = threadIdx.x; i < tv.npix; i += NT) {
+            const double v = chain_value(pg, upto, params, heq, tv.raw(i));
+            if (in_set(cs, tv, i, v)) { c2 += 1.0; s2 += v; }
+        }
+        c2 = block_sum(s, c2); s2 = block_sum(s, s2);
+        const unsigned long long n2 = (unsigned long long)c2;
+        const bool changed = n2 != n;
+        n = n2; sum = s2;
+        fresh = !changed;
+        if (!changed) break;
+    }
+    if (!fresh && n > 0) {                   // stopped by maxiters: statistics of the final survivors
+        const double mean = sum / (double)n;
+        double ssq = 0.0;
+        for (int i = threadIdx.x; i < tv.npix; i += NT) {
+            const double v = chain_value(pg, upto, params, heq, tv.raw(i));
+            if (in_set(cs, tv, i, v)) { const double d = v - mean; ssq += d * d; }
+        }
+        ssq = block_sum(s, ssq);
+        r.mean = mean; r.std = sqrt(ssq / (double)n); r.median = set_median(s, tv, pg, upto, params, heq, cs, n); r.n = n;
+    }
+    if (n == 0) r.n = 0;
+    return r;
+}
+
+// astropy ZScaleInterval.get_limits (nsamples 1000, max_reject 0.5, min_npixels 5, krej 2.5, max_iterations 5)
+__device__ void zscale_run(Smem& s, const TileView& tv, const PreProgram& pg, int upto, const double* params, const double* heq,
+                           double contrast, double* vmin_out, double* vmax_out) {
+    const int t = threadIdx.x;
+    int stride = (int)fmax(1.0, (double)tv.npix / 1000.0);
+    int ns = (tv.npix + stride - 1) / stride;
+    if (ns > 1000) ns = 1000;
+    s.zs[t] = t < ns ? chain_value(pg, upto, params, heq, tv.raw(t * stride)) : INFINITY;
+    __syncthreads();
+    for (int kk = 2; kk <= 1024; kk <<= 1)
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            const int ixj = t ^ j;
+            if (ixj > t) {
+                const bool up = (t & kk) == 0;
+                const double a = s.zs[t], b = s.zs[ixj];
+                if ((a > b) == up) { s.zs[t] = b; s.zs[ixj] = a; }
+            }
+            __syncthreads();
+        }
+    const int npix = ns;
+    double vmin = s.zs[0], vmax = s.zs[npix - 1];
+    int minpix = (int)(npix * 0.5); if (minpix < 5) minpix = 5;
+    int ngrow = (int)(npix * 0.01); if (ngrow < 1) ngrow = 1;
+    int ngood = npix, last = npix + 1;
+    s.bad[t] = 0;
+    __syncthreads();
+    double slope = 0.0;
+    const double y = t < npix ? s.zs[t] : 0.0, x = (double)t;
+    for (int it = 0; it < 5; ++it) {
+        if (ngood >= last || ngood < minpix) break;
+        const double w = (t < npix && !s.bad[t]) ? 1.0 : 0.0;
+        // weighted straight-line least squares (np.polyfit deg 1, w in {0,1}) in centred form
+        const double sw = block_sum(s, w), sx = block_sum(s, w * x), sy = block_sum(s, w * y);
+        const double xm = sx / sw, ym = sy / sw;
+        const double sxx = block_sum(s, w * (x - xm) * (x - xm)), sxy = block_sum(s, w * (x - xm) * (y - ym));
+        slope = sxy / sxx;
+        const double icpt = ym - slope * xm;
+        const double flat = y - (slope * x + icpt);
+        const double fm = block_sum(s, w * flat) / sw;
+        const double var = block_sum(s, w * (flat - fm) * (flat - fm)) / sw;
+        const double thr = 2.5 * sqrt(var);
+        if (t < npix && (flat < -thr || flat > thr)) s.bad[t] = 1;
+        __syncthreads();
+        // np.convolve(badpix, ones(ngrow), 'same'): OR over j in [i + c - (ngrow-1), i + c], c = (ngrow-1)//2
+        unsigned char nb = 0;
+        if (t < npix) {
+            const int c = (ngrow - 1) / 2;
+            int j0 = t + c - (ngrow - 1), j1 = t + c;
+            if (j0 < 0) j0 = 0;
+            if (j1 > npix - 1) j1 = npix - 1;
+            for (int j = j0; j <= j1; ++j) nb |= s.bad[j];
+        }
+        s.bad2[t] = nb;
+        __syncthreads();
+        s.bad[t] = s.bad2[t];
+        __syncthreads();
+        last = ngood;
+        ngood = (int)block_sum(s, (t < npix && !s.bad[t]) ? 1.0 : 0.0);
+    }
+    if (ngood >= minpix) {
+        if (contrast > 0.0) slope = slope / contrast;
+        const int center = (npix - 1) / 2;
+        const double median = (npix & 1) ? s.zs[(npix - 1) / 2] : 0.5 * (s.zs[npix / 2 - 1] + s.zs[npix / 2]);
+        const double lo = median - (double)(center - 1) * slope, hi = median + (double)(npix - center) * slope;
+        if (lo > vmin) vmin = lo;
+        if (hi < vmax) vmax = hi;
+    }
+    *vmin_out = vmin; *vmax_out = vmax;
+    __syncthreads();
+}
+
+// skimage equalize_hist tables: np.histogram(image, 256) over [min,max] (zeros included), cdf, bin centres
+__device__ void histeq_run(Smem& s, const TileView& tv, const PreProgram& pg, int upto, const double* params, double* heq) {
+    double mn = INFINITY, mx = -INFINITY;
+    for (int i = threadIdx.x; i < tv.npix; i += NT) {
+        const double v = chain_value(pg, upto, params, heq, tv.raw(i));
+        mn = fmin(mn, v); mx = fmax(mx, v);
+    }
+    mn = block_min(s, mn); mx = block_max(s, mx);
+    double first = mn, last = mx;
+    if (first == last) { first -= 0.5; last += 0.5; }
+    const double step = (last - first) / 256.0;
+    auto edge = [&](int i) { return i == 256 ? last : (double)i * step + first; };       // np.linspace
+    for (int i = threadIdx.x; i < 256; i += NT) s.hist[i] = 0u;
+    __syncthreads();
+    for (int i = threadIdx.x; i < tv.npix; i += NT) {
+        const double v = chain_value(pg, upto, params, heq, tv.raw(i));
+        int idx = (int)(((v - first) / (last - first)) * 256.0);
+        if (idx == 256) idx = 255;
+        if (idx < 0) idx = 0;
+        if (idx > 255) idx = 255;
+        if (v < edge(idx)) idx -= 1;
+        else if (v >= edge(idx + 1) && idx != 255) idx += 1;
+        atomicAdd(&s.hist[idx], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long c = 0ull;
+        for (int i = 0; i < 256; ++i) { c += s.hist[i]; s.zs[i] = (double)c; }
+        for (int i = 0; i < 256; ++i) {
+            heq[256 + i] = s.zs[i] / (double)c;
+            heq[i] = (edge(i) + edge(i + 1)) / 2.0;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------- statistics kernel
+__global__ __launch_bounds__(NT) void pre_stats_kernel(const PreArgs a) {
+    __shared__ Smem s;
+    const int b = blockIdx.x, p = blockIdx.y;
+    const PreProgram& pg = a.prog[p];
+    double* params = a.params + ((size_t)b * 3 + p) * PSTRIDE;
+    double* heq = a.histeq + ((size_t)b * 3 + p) * HEQ_STRIDE;
+    const int* tl = a.tiles + 4 * b;
+    TileView tv{a.mosaic + (size_t)tl[1] * a.MW + tl[0], a.MW, a.tw, a.th, a.tw * a.th};
+    int status = 0;
+    for (int k = 0; k < pg.n; ++k) {
+        const PreStage& st = pg.st[k];
+        double o0 = 0, o1 = 0, o2 = 0, o3 = 0;
+        if (st.op == OP_BKG) {
+            const ClipStats r = sigma_clip_run(s, tv, pg, k, params, heq, st.p0, st.p0, st.flag, st.p1);
+            o0 = r.mean; if (r.n == 0) status = 1;
+        } else if (st.op == OP_SHIFT) {
+            const ClipStats r = sigma_clip_run(s, tv, pg, k, params, heq, st.p0, st.p0, 0, 0.0);
+            o0 = r.mean + st.p0 * r.std; o1 = r.mean; o2 = r.std; if (r.n == 0) status = 1;
+        } else if (st.op == OP_CLIP) {
+            // astropy: `sigma_lower or sigma` -- a 0 falls back to the default sigma = 3
+            const double slo = st.p0 != 0.0 ? st.p0 : 3.0, sup = st.p1 != 0.0 ? st.p1 : 3.0;
+            const ClipStats r = sigma_clip_run(s, tv, pg, k, params, heq, slo, sup, 0, 0.0);
+            o0 = r.lo; o1 = r.hi; if (r.n == 0 && isnan(r.lo)) status = 1;
+        } else if (st.op == OP_ZSCALE) {
+            zscale_run(s, tv, pg, k, params, heq, st.p0, &o0, &o1);
+        } else if (st.op == OP_HISTEQ) {
+            histeq_run(s, tv, pg, k, params, heq);
+        } else if (st.op == OP_MINMAX) {
+            double mn = INFINITY, mx = -INFINITY;
+            for (int i = threadIdx.x; i < tv.npix; i += NT) {
+                const double v = chain_value(pg, k, params, heq, tv.raw(i));
+                if (cond_of(v)) { mn = fmin(mn, v); mx = fmax(mx, v); }
+            }
+            o0 = block_min(s, mn); o1 = block_max(s, mx); o2 = st.p0; o3 = st.p1;
+            if (!(o0 <= o1)) status = 1;           // no non-zero finite pixel: the stage returns None (preprocessing.py:101-103)
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { params[k * 4] = o0; params[k * 4 + 1] = o1; params[k * 4 + 2] = o2; params[k * 4 + 3] = o3; }
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && status) atomicMax(a.status + b, status);
+}
+
+// ---------------------------------------------------------------------------------------- apply + letterbox + pack
+__device__ __forceinline__ void tile_channels(const PreArgs& a, int b, double raw, double out[3]) {
+    if (a.nprog == 0) { out[0] = out[1] = out[2] = raw; return; }
+    for (int c = 0; c < 3; ++c) {
+        const int p = a.nprog == 1 ? 0 : c;
+        if (a.nprog == 1 && c > 0) { out[c] = out[0]; continue; }
+        out[c] = chain_value(a.prog[p], a.prog[p].n, a.params + ((size_t)b * 3 + p) * PSTRIDE,
+                             a.histeq + ((size_t)b * 3 + p) * HEQ_STRIDE, raw);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pre_pack_kernel(const PreArgs a) {
+    typedef T vec4 __attribute__((ext_vector_type(4)));
+    const int b = blockIdx.y;
+    const int* tl = a.tiles + 4 * b;
+    const float* base = a.mosaic + (size_t)tl[1] * a.MW + tl[0];
+    const int npx = a.H * a.W;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < npx; i += gridDim.x * 256) {
+        const int Y = i / a.W, X = i - Y * a.W;
+        const int y = Y - a.top, x = X - a.left;
+        float v[3] = {114.0f / 255.0f, 114.0f / 255.0f, 114.0f / 255.0f};
+        if ((unsigned)y < (unsigned)a.th && (unsigned)x < (unsigned)a.tw) {
+            double ch[3];
+            tile_channels(a, b, (double)base[(size_t)y * a.MW + x], ch);
+            for (int c = 0; c < 3; ++c) v[c] = (float)ch[c] / 255.0f;
+        }
+        // network channel c = image channel 2-c (ultralytics treats the array as BGR and flips it)
+        vec4 o = {(T)v[2], (T)v[1], (T)v[0], (T)0.0f};
+        reinterpret_cast<vec4*>(a.out)[(size_t)b * npx + i] = o;
+    }
+}
+
+// resize path: first the preprocessed tile in float64 planes, then cv2-style bilinear (float32 coordinates/weights)
+__global__ __launch_bounds__(256) void pre_plane_kernel(const PreArgs a) {
+    const int b = blockIdx.y;
+    const int* tl = a.tiles + 4 * b;
+    const float* base = a.mosaic + (size_t)tl[1] * a.MW + tl[0];
+    const int npx = a.th * a.tw;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < npx; i += gridDim.x * 256) {
+        const int y = i / a.tw, x = i - y * a.tw;
+        double ch[3];
+        tile_channels(a, b, (double)base[(size_t)y * a.MW + x], ch);
+        for (int c = 0; c < 3; ++c) a.scratch[((size_t)b * 3 + c) * npx + i] = ch[c];
+    }
+}
+
+__device__ __forceinline__ void lin_axis(int d, int nsrc, int ndst, int* i0, int* i1, double* w) {
+    const double scale = (double)nsrc / (double)ndst;
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s0 = (int)floorf(f);
+    float al = f - (float)s0;
+    if (s0 < 0) { s0 = 0; al = 0.0f; }
+    if (s0 >= nsrc - 1) { s0 = nsrc - 1; al = 0.0f; }
+    *i0 = s0; *i1 = s0 + 1 < nsrc ? s0 + 1 : nsrc - 1; *w = (double)al;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pre_resize_pack_kernel(const PreArgs a) {
+    typedef T vec4 __attribute__((ext_vector_type(4)));
+    const int b = blockIdx.y;
+    const int npx = a.H * a.W, spx = a.th * a.tw;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < npx; i += gridDim.x * 256) {
+        const int Y = i / a.W, X = i - Y * a.W;
+        const int y = Y - a.top, x = X - a.left;
+        float v[3] = {114.0f / 255.0f, 114.0f / 255.0f, 114.0f / 255.0f};
+        if ((unsigned)y < (unsigned)a.new_h && (unsigned)x < (unsigned)a.new_w) {
+            int y0, y1, x0, x1; double wy, wx;
+            lin_axis(y, a.th, a.new_h, &y0, &y1, &wy);
+            lin_axis(x, a.tw, a.new_w, &x0, &x1, &wx);
+            for (int c = 0; c < 3; ++c) {
+                const double* pl = a.scratch + ((size_t)b * 3 + c) * spx;
+                const double r0 = pl[y0 * a.tw + x0] * (1.0 - wx) + pl[y0 * a.tw + x1] * wx;
+                const double r1 = pl[y1 * a.tw + x0] * (1.0 - wx) + pl[y1 * a.tw + x1] * wx;
+                v[c] = (float)(r0 * (1.0 - wy) + r1 * wy) / 255.0f;
+            }
+        }
+        vec4 o = {(T)v[2], (T)v[1], (T)v[0], (T)0.0f};
+        reinterpret_cast<vec4*>(a.out)[(size_t)b * npx + i] = o;
+    }
+}
+
+// Analyzer.predict's "channel has constant value" test, which indexes ROWS 0..2 (evaluation.py:171-176)
+__global__ __launch_bounds__(256) void pre_rowcheck_kernel(const PreArgs a) {
+    __shared__ double smn[4], smx[4];
+    const int b = blockIdx.x;
+    const int* tl = a.tiles + 4 * b;
+    const float* base = a.mosaic + (size_t)tl[1] * a.MW + tl[0];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int bad = 0;
+    for (int row = 0; row < 3 && row < a.th; ++row) {
+        double mn = INFINITY, mx = -INFINITY;
+        for (int x = threadIdx.x; x < a.tw; x += 256) {
+            double ch[3];
+            tile_channels(a, b, (double)base[(size_t)row * a.MW + x], ch);
+            for (int c = 0; c < 3; ++c) { mn = fmin(mn, ch[c]); mx = fmax(mx, ch[c]); }
+        }
+        mn = wave_min(mn); mx = wave_max(mx);
+        __syncthreads();
+        if (lane == 0) { smn[w] = mn; smx[w] = mx; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int k = 1; k < 4; ++k) { smn[0] = fmin(smn[0], smn[k]); smx[0] = fmax(smx[0], smx[k]); }
+            if (smn[0] == smx[0]) bad = 1;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && bad && a.status[b] == 0) a.status[b] = 2;
+}
+
+hipError_t launch_preproc(const PreArgs& a, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(a.status, 0, a.B * sizeof(int), s);
+    if (e != hipSuccess) return e;
+    if (a.nprog > 0) hipLaunchKernelGGL(pre_stats_kernel, dim3(a.B, a.nprog), dim3(NT), 0, s, a);
+    hipLaunchKernelGGL(pre_rowcheck_kernel, dim3(a.B), dim3(256), 0, s, a);
+    const int npx = a.H * a.W;
+    int gx = (npx + 255) / 256; if (gx > 1024) gx = 1024;
+    if (a.scratch) {
+        int gs = (a.th * a.tw + 255) / 256; if (gs > 1024) gs = 1024;
+        hipLaunchKernelGGL(pre_plane_kernel, dim3(gs, a.B), dim3(256), 0, s, a);
+        if (a.out_prec == PREC_F16) hipLaunchKernelGGL(pre_resize_pack_kernel<_Float16>, dim3(gx, a.B), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(pre_resize_pack_kernel<float>, dim3(gx, a.B), dim3(256), 0, s, a);
+    } else {
+        if (a.out_prec == PREC_F16) hipLaunchKernelGGL(pre_pack_kernel<_Float16>, dim3(gx, a.B), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(pre_pack_kernel<float>, dim3(gx, a.B), dim3(256), 0, s, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_letterbox_pack(const PreArgs& a, hipStream_t s) {
+    const int npx = a.H * a.W;
+    int gx = (npx + 255) / 256; if (gx > 1024) gx = 1024;
+    if (a.out_prec == PREC_F16) hipLaunchKernelGGL(pre_resize_pack_kernel<_Float16>, dim3(gx, a.B), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(pre_resize_pack_kernel<float>, dim3(gx, a.B), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------- mosaic ingest
+__global__ __launch_bounds__(256) void mosaic_prepare_kernel(float* d, size_t n, int big_endian) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        unsigned u = reinterpret_cast<unsigned*>(d)[i];
+        if (big_endian) u = __builtin_bswap32(u);
+        float f = __uint_as_float(u);
+        if (!isfinite(f)) f = 0.0f;
+        d[i] = f;
+    }
+}
+
+hipError_t launch_mosaic_prepare(float* data, size_t n, int big_endian, hipStream_t s) {
+    size_t g = (n + 255) / 256; if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(mosaic_prepare_kernel, dim3((unsigned)g), dim3(256), 0, s, data, n, big_endian);
+    return hipGetLastError();
+}
+
+}  // namespace cy

@@ -1,0 +1,491 @@
+// Runtime behind the C-ABI (include/caesar_yolo_hip.h): context, weight upload, workspace, and the host loops that
+// enqueue the gfx950 kernels.  One context per GPU / per process (one process per GPU under torch.distributed).
+#include "../../include/caesar_yolo_hip.h"
+#include "cy_kernels.h"
+#include "cy_plan.h"
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace cy;
+
+struct DevConv { void* w = nullptr; float* bias = nullptr; size_t wbytes = 0; float* stem_w = nullptr; };
+
+struct cy_ctx {
+    int device = 0;
+    cy_config cfg{};
+    Precision prec = PREC_F16;
+    std::string err;
+    bool loaded = false;
+    Plan plan;
+    std::vector<std::string> names;
+    std::vector<DevConv> dconv;
+    // workspace
+    char* ws = nullptr; size_t ws_bytes = 0;           // activations
+    std::vector<size_t> toff; std::vector<size_t> tbytes;   // per tensor, for the last forward geometry
+    int lastB = 0, lastH = 0, lastW = 0;
+    // stage buffers (sized at load for max_batch)
+    void* netin = nullptr; float* pred = nullptr;
+    float* cand = nullptr; int* cand_anchor = nullptr; int* cand_count = nullptr;
+    uint64_t* keys = nullptr; uint64_t* mask = nullptr;
+    float* det = nullptr; int* det_anchor = nullptr; int* det_count = nullptr; int* merge_err = nullptr;
+    int* out_src = nullptr;
+    int* d_tiles = nullptr; double* pre_params = nullptr; double* pre_histeq = nullptr; double* pre_scratch = nullptr;
+    size_t pre_scratch_elems = 0;
+    int cap = 0, cap_pow2 = 0;
+};
+
+namespace {
+thread_local std::string g_err;
+int fail(cy_ctx* c, int code, const std::string& m) { if (c) c->err = m; g_err = m; return code; }
+#define HIPCHK(c, x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(c, CY_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline size_t esize(Precision p) { return p == PREC_F16 ? 2 : 4; }
+
+int py_round_half_even(double x) {
+    double f = std::floor(x), d = x - f;
+    if (d > 0.5) return (int)f + 1;
+    if (d < 0.5) return (int)f;
+    return (((long)f) % 2 == 0) ? (int)f : (int)f + 1;
+}
+
+size_t tensor_elems_per_tile(const Plan& p, int H, int W) {
+    size_t t = 0;
+    for (auto& x : p.tensors) t += (size_t)(H >> x.level) * (W >> x.level) * x.C;
+    return t;
+}
+
+void free_all(cy_ctx* c) {
+    for (auto& d : c->dconv) { if (d.w) hipFree(d.w); if (d.bias) hipFree(d.bias); if (d.stem_w) hipFree(d.stem_w); }
+    c->dconv.clear();
+    void* ptrs[] = {c->ws, c->netin, c->pred, c->cand, c->cand_anchor, c->cand_count, c->keys, c->mask, c->det,
+                    c->det_anchor, c->det_count, c->merge_err, c->out_src, c->d_tiles, c->pre_params, c->pre_histeq,
+                    c->pre_scratch};
+    for (void* p : ptrs) if (p) hipFree(p);
+    c->ws = nullptr; c->netin = nullptr; c->pred = nullptr; c->cand = nullptr; c->cand_anchor = nullptr;
+    c->cand_count = nullptr; c->keys = nullptr; c->mask = nullptr; c->det = nullptr; c->det_anchor = nullptr;
+    c->det_count = nullptr; c->merge_err = nullptr; c->out_src = nullptr; c->d_tiles = nullptr;
+    c->pre_params = nullptr; c->pre_histeq = nullptr; c->pre_scratch = nullptr;
+}
+
+struct Reader {
+    const unsigned char* p; size_t n, o = 0; bool bad = false;
+    uint32_t u32() { if (o + 4 > n) { bad = true; return 0; } uint32_t v; memcpy(&v, p + o, 4); o += 4; return v; }
+    std::string str(uint32_t len) { if (o + len > n) { bad = true; return ""; } std::string s((const char*)p + o, len); o += (len + 3) / 4 * 4; return s; }
+    const float* f32(size_t cnt) { if (o + 4 * cnt > n) { bad = true; return nullptr; } const float* r = (const float*)(p + o); o += 4 * cnt; return r; }
+};
+
+int upload_weights(cy_ctx* c, const void* buf, size_t nbytes) {
+    Reader r{(const unsigned char*)buf, nbytes};
+    if (nbytes < 24 || memcmp(buf, "CYW1", 4) != 0) return fail(c, CY_ERR_IO, "not a CYW1 weight file");
+    r.o = 4;
+    if (r.u32() != 1) return fail(c, CY_ERR_IO, "unsupported CYW version");
+    const char scale = (char)r.p[r.o]; r.o += 4;
+    const uint32_t nc = r.u32(), nconv = r.u32(), nnames = r.u32();
+    Plan plan = build_plan(scale, (int)nc);
+    if (!plan.ok) return fail(c, CY_ERR_UNSUPPORTED, plan.err);
+    if (plan.convs.size() != nconv) return fail(c, CY_ERR_IO, "weight file conv count does not match the graph");
+    std::vector<std::string> names;
+    for (uint32_t i = 0; i < nnames; ++i) { uint32_t l = r.u32(); names.push_back(r.str(l)); }
+    HIPCHK(c, hipSetDevice(c->device));
+    free_all(c);
+    c->dconv.resize(nconv);
+    std::vector<char> packed;
+    for (uint32_t i = 0; i < nconv; ++i) {
+        const uint32_t co = r.u32(), ci = r.u32(), k = r.u32(), s = r.u32(), act = r.u32(), nl = r.u32();
+        const std::string name = r.str(nl);
+        const ConvDesc& d = plan.convs[i];
+        if (r.bad) return fail(c, CY_ERR_IO, "truncated weight file");
+        if (name != d.name || (int)co != d.cout || (int)ci != d.cin || (int)k != d.k || (int)s != d.s || (int)act != d.act)
+            return fail(c, CY_ERR_IO, "weight file layer " + name + " does not match graph layer " + d.name);
+        const float* W = r.f32((size_t)co * ci * k * k);
+        const float* b = r.f32(co);
+        if (r.bad) return fail(c, CY_ERR_IO, "truncated weight file");
+        DevConv& dc = c->dconv[i];
+        const int cp = (co + 127) / 128 * 128;
+        std::vector<float> bias(cp, 0.0f);
+        memcpy(bias.data(), b, 4 * co);
+        HIPCHK(c, hipMalloc(&dc.bias, 4 * cp));
+        HIPCHK(c, hipMemcpy(dc.bias, bias.data(), 4 * cp, hipMemcpyHostToDevice));
+        if (i == 0) {   // stem: [27][Cout] fp32, t = (kh*3+kw)*3 + c over the 3 network input channels
+            if (co > 64 || co % 16) return fail(c, CY_ERR_UNSUPPORTED, "stem width not supported by the gfx950 stem kernel");
+            std::vector<float> sw(27 * co);
+            for (uint32_t o = 0; o < co; ++o) for (int cch = 0; cch < 3; ++cch) for (int t = 0; t < 9; ++t)
+                sw[(size_t)(t * 3 + cch) * co + o] = W[((size_t)o * 3 + cch) * 9 + t];
+            HIPCHK(c, hipMalloc(&dc.stem_w, 4 * sw.size()));
+            HIPCHK(c, hipMemcpy(dc.stem_w, sw.data(), 4 * sw.size(), hipMemcpyHostToDevice));
+            continue;
+        }
+        if (ci % 8) return fail(c, CY_ERR_UNSUPPORTED, "conv input channels must be a multiple of 8: " + name);
+        dc.wbytes = packed_weight_bytes(c->prec, co, ci, k);
+        packed.resize(dc.wbytes);
+        pack_weights(c->prec, W, co, ci, k, packed.data());
+        HIPCHK(c, hipMalloc(&dc.w, dc.wbytes));
+        HIPCHK(c, hipMemcpy(dc.w, packed.data(), dc.wbytes, hipMemcpyHostToDevice));
+    }
+    c->plan = plan; c->names = names;
+    // ---- workspace for (max_batch, max_h, max_w)
+    const cy_config& g = c->cfg;
+    const size_t es = esize(c->prec);
+    size_t act = 0;
+    for (auto& t : plan.tensors) act += align_up((size_t)g.max_batch * (g.max_h >> t.level) * (g.max_w >> t.level) * t.C * es, 256);
+    c->ws_bytes = act;
+    HIPCHK(c, hipMalloc(&c->ws, c->ws_bytes));
+    const int A = cy_num_anchors(g.max_h, g.max_w);
+    c->cap = g.max_cand > 0 ? g.max_cand : 8192;
+    if (c->cap > 30000) c->cap = 30000;
+    c->cap = (c->cap + 63) / 64 * 64;
+    c->cap_pow2 = 1; while (c->cap_pow2 < c->cap) c->cap_pow2 <<= 1;
+    const size_t Bm = g.max_batch;
+    HIPCHK(c, hipMalloc(&c->netin, Bm * g.max_h * g.max_w * 4 * es));
+    HIPCHK(c, hipMalloc(&c->pred, Bm * A * (64 + nc) * sizeof(float)));
+    HIPCHK(c, hipMalloc(&c->cand, Bm * c->cap * 6 * sizeof(float)));
+    HIPCHK(c, hipMalloc(&c->cand_anchor, Bm * c->cap * sizeof(int)));
+    HIPCHK(c, hipMalloc(&c->cand_count, Bm * sizeof(int)));
+    HIPCHK(c, hipMalloc(&c->keys, Bm * c->cap_pow2 * sizeof(uint64_t)));
+    HIPCHK(c, hipMalloc(&c->mask, Bm * (size_t)c->cap * (c->cap / 64) * sizeof(uint64_t)));
+    HIPCHK(c, hipMalloc(&c->det, Bm * CY_MAX_DET * 6 * sizeof(float)));
+    HIPCHK(c, hipMalloc(&c->det_anchor, Bm * CY_MAX_DET * sizeof(int)));
+    HIPCHK(c, hipMalloc(&c->det_count, Bm * sizeof(int)));
+    HIPCHK(c, hipMalloc(&c->merge_err, Bm * sizeof(int)));
+    HIPCHK(c, hipMalloc(&c->out_src, Bm * CY_MAX_DET * sizeof(int)));
+    HIPCHK(c, hipMalloc(&c->d_tiles, Bm * 4 * sizeof(int)));
+    HIPCHK(c, hipMalloc(&c->pre_params, Bm * 3 * CY_MAX_STAGES * 4 * sizeof(double)));
+    HIPCHK(c, hipMalloc(&c->pre_histeq, Bm * 3 * 520 * sizeof(double)));
+    c->pre_scratch_elems = Bm * 3 * (size_t)g.max_h * g.max_w;
+    HIPCHK(c, hipMalloc(&c->pre_scratch, c->pre_scratch_elems * sizeof(double)));
+    c->loaded = true;
+    return CY_OK;
+}
+
+int layout_tensors(cy_ctx* c, int B, int H, int W) {
+    const size_t es = esize(c->prec);
+    c->toff.assign(c->plan.tensors.size(), 0);
+    c->tbytes.assign(c->plan.tensors.size(), 0);
+    size_t off = 0;
+    for (size_t i = 0; i < c->plan.tensors.size(); ++i) {
+        const Tensor& t = c->plan.tensors[i];
+        const size_t b = (size_t)B * (H >> t.level) * (W >> t.level) * t.C * es;
+        c->toff[i] = off; c->tbytes[i] = b;
+        off += align_up(b, 256);
+        if (b >= 0xFFFFFF00ull) return fail(c, CY_ERR_ARG, "a tensor exceeds the 4 GiB buffer-addressing limit; lower the batch");
+    }
+    if (off > c->ws_bytes) return fail(c, CY_ERR_ARG, "batch/shape exceeds the workspace sized at cy_create");
+    c->lastB = B; c->lastH = H; c->lastW = W;
+    return CY_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int cy_create(int device, const cy_config* cfg, cy_ctx** out) {
+    if (!cfg || !out) return fail(nullptr, CY_ERR_ARG, "null argument");
+    if (cfg->max_batch < 1 || cfg->max_h < 32 || cfg->max_w < 32 || cfg->max_h % 32 || cfg->max_w % 32)
+        return fail(nullptr, CY_ERR_ARG, "max_batch >= 1 and max_h/max_w multiples of 32 required");
+    if (cfg->precision != CY_F16 && cfg->precision != CY_F32) return fail(nullptr, CY_ERR_ARG, "bad precision");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n)
+        return fail(nullptr, CY_ERR_HIP, "no such HIP device (this library has no CPU fallback)");
+    cy_ctx* c = new cy_ctx();
+    c->device = device; c->cfg = *cfg; c->prec = cfg->precision == CY_F16 ? PREC_F16 : PREC_F32;
+    *out = c;
+    return CY_OK;
+}
+
+int cy_destroy(cy_ctx* c) {
+    if (!c) return CY_OK;
+    hipSetDevice(c->device);
+    free_all(c);
+    delete c;
+    return CY_OK;
+}
+
+const char* cy_last_error(const cy_ctx* c) { return c ? c->err.c_str() : g_err.c_str(); }
+
+int cy_load_weights_mem(cy_ctx* c, const void* buf, size_t nbytes) {
+    if (!c || !buf) return fail(c, CY_ERR_ARG, "null argument");
+    return upload_weights(c, buf, nbytes);
+}
+
+int cy_load_weights(cy_ctx* c, const char* path) {
+    if (!c || !path) return fail(c, CY_ERR_ARG, "null argument");
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(c, CY_ERR_IO, std::string("cannot open ") + path);
+    fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
+    std::vector<char> buf(n);
+    const size_t got = fread(buf.data(), 1, n, f);
+    fclose(f);
+    if ((long)got != n) return fail(c, CY_ERR_IO, "short read");
+    return upload_weights(c, buf.data(), buf.size());
+}
+
+int cy_num_classes(const cy_ctx* c) { return c && c->loaded ? c->plan.nc : -1; }
+const char* cy_class_name(const cy_ctx* c, int i) {
+    if (!c || !c->loaded || i < 0 || i >= (int)c->names.size()) return nullptr;
+    return c->names[i].c_str();
+}
+
+int cy_plan_num_convs(char scale, int nc) { Plan p = build_plan(scale, nc); return p.ok ? (int)p.convs.size() : CY_ERR_ARG; }
+int cy_plan_conv_desc(char scale, int nc, int idx, cy_conv_desc* out) {
+    Plan p = build_plan(scale, nc);
+    if (!p.ok || !out || idx < 0 || idx >= (int)p.convs.size()) return CY_ERR_ARG;
+    const ConvDesc& d = p.convs[idx];
+    memset(out, 0, sizeof(*out));
+    strncpy(out->name, d.name.c_str(), sizeof(out->name) - 1);
+    out->cin = d.cin; out->cout = d.cout; out->k = d.k; out->s = d.s; out->act = d.act;
+    return CY_OK;
+}
+
+int cy_letterbox_geometry(int h0, int w0, int imgsz, cy_letterbox* o) {
+    // ultralytics LetterBox(auto=True, scaleup=True, center=True, stride=32): SURVEY.md Appendix A.1 step 2
+    if (!o || h0 < 1 || w0 < 1 || imgsz < 32) return CY_ERR_ARG;
+    const double r = std::fmin((double)imgsz / h0, (double)imgsz / w0);
+    o->new_w = py_round_half_even(w0 * r); o->new_h = py_round_half_even(h0 * r);
+    double dw = (imgsz - o->new_w) % 32, dh = (imgsz - o->new_h) % 32;
+    if (dw < 0) dw += 32;
+    if (dh < 0) dh += 32;
+    dw /= 2; dh /= 2;
+    o->top = py_round_half_even(dh - 0.1); o->left = py_round_half_even(dw - 0.1);
+    const int bottom = py_round_half_even(dh + 0.1), right = py_round_half_even(dw + 0.1);
+    o->H = o->new_h + o->top + bottom; o->W = o->new_w + o->left + right;
+    return CY_OK;
+}
+
+int cy_num_anchors(int H, int W) { int n = 0; for (int s = 8; s <= 32; s *= 2) n += ((H + s - 1) / s) * ((W + s - 1) / s); return n; }
+size_t cy_pred_elems(const cy_ctx* c, int B, int H, int W) {
+    return c && c->loaded ? (size_t)B * cy_num_anchors(H, W) * (64 + c->plan.nc) : 0;
+}
+
+int cy_mosaic_prepare(cy_ctx* c, float* d_data, size_t n, int big_endian, void* stream) {
+    if (!c || !d_data) return fail(c, CY_ERR_ARG, "null argument");
+    HIPCHK(c, launch_mosaic_prepare(d_data, n, big_endian, (hipStream_t)stream));
+    return CY_OK;
+}
+
+int cy_forward(cy_ctx* c, const void* d_netin, int B, int H, int W, float* d_pred, void* stream) {
+    if (!c || !c->loaded) return fail(c, CY_ERR_STATE, "weights not loaded");
+    if (!d_netin || !d_pred || B < 1 || H % 32 || W % 32 || H < 32 || W < 32) return fail(c, CY_ERR_ARG, "bad forward arguments");
+    int rc = layout_tensors(c, B, H, W);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const Plan& p = c->plan;
+    const size_t es = esize(c->prec);
+    const int A = cy_num_anchors(H, W);
+    int a_off[3], acc = 0;
+    for (int l = 0; l < 3; ++l) { a_off[l] = acc; acc += (H >> (3 + l)) * (W >> (3 + l)); }
+    auto tptr = [&](int t) -> char* { return t == 0 ? (char*)const_cast<void*>(d_netin) : c->ws + c->toff[t]; };
+    for (const Op& o : p.ops) {
+        if (o.kind == OPK_STEM) {
+            const Tensor& ti = p.tensors[o.in0]; const Tensor& to = p.tensors[o.out];
+            StemArgs a{};
+            a.in = tptr(o.in0); a.out = tptr(o.out); a.w = c->dconv[o.conv].stem_w; a.bias = c->dconv[o.conv].bias;
+            a.B = B; a.Hi = H >> ti.level; a.Wi = W >> ti.level; a.Ho = H >> to.level; a.Wo = W >> to.level;
+            a.Cout = p.convs[o.conv].cout; a.out_ct = to.C; a.out_coff = o.out_coff;
+            HIPCHK(c, launch_stem(c->prec, a, s));
+        } else if (o.kind == OPK_POOL) {
+            const Tensor& t = p.tensors[o.in0];
+            PoolArgs a{};
+            a.src = tptr(o.in0); a.dst = tptr(o.out); a.ct = t.C; a.src_coff = o.in0_coff; a.dst_coff = o.out_coff;
+            a.C = o.c0; a.B = B; a.H = H >> t.level; a.W = W >> t.level;
+            HIPCHK(c, launch_pool5(c->prec, a, s));
+        } else {
+            const ConvDesc& d = p.convs[o.conv];
+            ConvArgs a{};
+            const Tensor& t0 = p.tensors[o.in0];
+            a.in0 = tptr(o.in0); a.in0_ct = t0.C; a.in0_coff = o.in0_coff; a.c0 = o.c0; a.up0 = o.up0;
+            a.in0_bytes = (uint32_t)(o.in0 == 0 ? (size_t)B * H * W * 4 * es : c->tbytes[o.in0]);
+            int lev_in = o.up0 ? t0.level - 1 : t0.level;
+            if (o.in1 >= 0) {
+                const Tensor& t1 = p.tensors[o.in1];
+                a.in1 = tptr(o.in1); a.in1_ct = t1.C; a.in1_coff = o.in1_coff; a.c1 = o.c1; a.in1_bytes = (uint32_t)c->tbytes[o.in1];
+                lev_in = t1.level;
+            }
+            a.wgt = c->dconv[o.conv].w; a.wgt_bytes = (uint32_t)c->dconv[o.conv].wbytes; a.bias = c->dconv[o.conv].bias;
+            a.B = B; a.Hi = H >> lev_in; a.Wi = W >> lev_in; a.k = d.k; a.s = d.s; a.act = d.act;
+            a.Ho = d.s == 2 ? a.Hi / 2 : a.Hi; a.Wo = d.s == 2 ? a.Wi / 2 : a.Wi;
+            a.Cin = d.cin; a.Cout = d.cout;
+            if (o.out >= 0) {
+                const Tensor& to = p.tensors[o.out];
+                a.out = tptr(o.out); a.out_ct = to.C; a.out_coff = o.out_coff; a.out_bs = a.Ho * a.Wo; a.out_ro = 0; a.out_f32 = 0;
+            } else {
+                a.out = d_pred; a.out_ct = 64 + p.nc; a.out_coff = o.pred_coff; a.out_bs = A; a.out_ro = a_off[o.pred_level]; a.out_f32 = 1;
+            }
+            if (o.res >= 0) { a.res = tptr(o.res); a.res_ct = p.tensors[o.res].C; a.res_coff = o.res_coff; }
+            HIPCHK(c, launch_conv(c->prec, a, s));
+        }
+    }
+    return CY_OK;
+}
+
+int cy_debug_read_conv(cy_ctx* c, const char* conv_name, float* h_out, size_t cap, int* dims4) {
+    if (!c || !c->loaded || !conv_name || !h_out) return fail(c, CY_ERR_ARG, "bad arguments");
+    if (c->lastB == 0) return fail(c, CY_ERR_STATE, "no forward has run");
+    const Plan& p = c->plan;
+    for (const Op& o : p.ops) {
+        if (o.kind == OPK_POOL || p.convs[o.conv].name != conv_name) continue;
+        if (o.out < 0) return fail(c, CY_ERR_UNSUPPORTED, "head outputs are read from d_pred");
+        const Tensor& t = p.tensors[o.out];
+        const int Ho = c->lastH >> t.level, Wo = c->lastW >> t.level, C = p.convs[o.conv].cout, B = c->lastB;
+        const size_t n = (size_t)B * C * Ho * Wo;
+        if (n > cap) return fail(c, CY_ERR_ARG, "output buffer too small");
+        HIPCHK(c, hipDeviceSynchronize());
+        std::vector<char> host(c->tbytes[o.out]);
+        HIPCHK(c, hipMemcpy(host.data(), c->ws + c->toff[o.out], host.size(), hipMemcpyDeviceToHost));
+        for (int b = 0; b < B; ++b) for (int h = 0; h < Ho; ++h) for (int w = 0; w < Wo; ++w) for (int ch = 0; ch < C; ++ch) {
+            const size_t src = (((size_t)b * Ho + h) * Wo + w) * t.C + o.out_coff + ch;
+            const float v = c->prec == PREC_F16 ? (float)reinterpret_cast<_Float16*>(host.data())[src]
+                                                : reinterpret_cast<float*>(host.data())[src];
+            h_out[(((size_t)b * C + ch) * Ho + h) * Wo + w] = v;
+        }
+        if (dims4) { dims4[0] = B; dims4[1] = C; dims4[2] = Ho; dims4[3] = Wo; }
+        return CY_OK;
+    }
+    return fail(c, CY_ERR_ARG, std::string("no such conv: ") + conv_name);
+}
+
+int cy_conv_bn_silu(cy_ctx* c, const void* d_in, int B, int Hi, int Wi, int Cin, const float* h_w, const float* h_b,
+                    int Cout, int k, int s, int act, const void* d_res, void* d_out, void* stream) {
+    if (!c || !d_in || !h_w || !h_b || !d_out) return fail(c, CY_ERR_ARG, "null argument");
+    if ((k != 1 && k != 3) || (s != 1 && s != 2) || Cin % 8 || B < 1) return fail(c, CY_ERR_ARG, "unsupported conv geometry");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t es = esize(c->prec);
+    const size_t wb = packed_weight_bytes(c->prec, Cout, Cin, k);
+    std::vector<char> packed(wb);
+    pack_weights(c->prec, h_w, Cout, Cin, k, packed.data());
+    const int cp = (Cout + 127) / 128 * 128;
+    std::vector<float> bias(cp, 0.0f);
+    memcpy(bias.data(), h_b, 4 * Cout);
+    void* dw = nullptr; float* db = nullptr;
+    HIPCHK(c, hipMalloc(&dw, wb));
+    HIPCHK(c, hipMalloc(&db, 4 * cp));
+    HIPCHK(c, hipMemcpy(dw, packed.data(), wb, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(db, bias.data(), 4 * cp, hipMemcpyHostToDevice));
+    ConvArgs a{};
+    const int pad = k / 2;
+    a.in0 = d_in; a.in0_ct = Cin; a.c0 = Cin; a.in0_bytes = (uint32_t)((size_t)B * Hi * Wi * Cin * es);
+    a.wgt = dw; a.wgt_bytes = (uint32_t)wb; a.bias = db;
+    a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ho = (Hi + 2 * pad - k) / s + 1; a.Wo = (Wi + 2 * pad - k) / s + 1;
+    a.Cin = Cin; a.Cout = Cout; a.k = k; a.s = s; a.act = act;
+    a.out = d_out; a.out_ct = Cout; a.out_bs = a.Ho * a.Wo;
+    if (d_res) { a.res = d_res; a.res_ct = Cout; }
+    hipError_t e = launch_conv(c->prec, a, (hipStream_t)stream);
+    hipError_t e2 = hipStreamSynchronize((hipStream_t)stream);
+    hipFree(dw); hipFree(db);
+    if (e != hipSuccess) return fail(c, CY_ERR_HIP, hipGetErrorString(e));
+    if (e2 != hipSuccess) return fail(c, CY_ERR_HIP, hipGetErrorString(e2));
+    return CY_OK;
+}
+
+int cy_preproc_params(cy_ctx* c, double* h_out, int B) {
+    if (!c || !c->loaded || !h_out || B < 1 || B > c->cfg.max_batch) return fail(c, CY_ERR_ARG, "bad arguments");
+    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipMemcpy(h_out, c->pre_params, (size_t)B * 3 * CY_MAX_STAGES * 4 * sizeof(double), hipMemcpyDeviceToHost));
+    return CY_OK;
+}
+
+int cy_preproc(cy_ctx* c, const float* d_mosaic, int MH, int MW, const int* h_tiles, int B, int th, int tw, int imgsz,
+               const cy_preproc_cfg* cfg, void* d_netin, int* d_status, void* stream) {
+    if (!c || !c->loaded) return fail(c, CY_ERR_STATE, "weights not loaded");
+    if (!d_mosaic || !h_tiles || !cfg || !d_netin || !d_status || B < 1 || B > c->cfg.max_batch)
+        return fail(c, CY_ERR_ARG, "bad preproc arguments");
+    if (cfg->nprog != 0 && cfg->nprog != 1 && cfg->nprog != 3) return fail(c, CY_ERR_ARG, "nprog must be 0, 1 or 3");
+    cy_letterbox lb;
+    if (cy_letterbox_geometry(th, tw, imgsz, &lb)) return fail(c, CY_ERR_ARG, "bad tile/imgsz");
+    if (lb.H > c->cfg.max_h || lb.W > c->cfg.max_w) return fail(c, CY_ERR_ARG, "letterboxed tile exceeds max_h/max_w of the context");
+    std::vector<int> t4(4 * B);
+    for (int b = 0; b < B; ++b) {
+        t4[4 * b] = h_tiles[2 * b]; t4[4 * b + 1] = h_tiles[2 * b + 1]; t4[4 * b + 2] = tw; t4[4 * b + 3] = th;
+        if (h_tiles[2 * b] < 0 || h_tiles[2 * b + 1] < 0 || h_tiles[2 * b] + tw > MW || h_tiles[2 * b + 1] + th > MH)
+            return fail(c, CY_ERR_ARG, "tile outside the mosaic");
+    }
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(c, hipMemcpyAsync(c->d_tiles, t4.data(), 4 * B * sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipStreamSynchronize(s));     // t4 is a stack-lifetime staging buffer
+    PreArgs a{};
+    a.mosaic = d_mosaic; a.MH = MH; a.MW = MW; a.tiles = c->d_tiles; a.B = B; a.th = th; a.tw = tw;
+    a.nprog = cfg->nprog;
+    for (int i = 0; i < 3; ++i) {
+        a.prog[i].n = cfg->prog[i].n;
+        if (a.prog[i].n < 0 || a.prog[i].n > MAX_STAGES) return fail(c, CY_ERR_ARG, "too many stages");
+        for (int j = 0; j < a.prog[i].n; ++j) {
+            const cy_pre_stage& st = cfg->prog[i].st[j];
+            a.prog[i].st[j] = PreStage{st.op, st.p0, st.p1, st.p2, st.flag};
+        }
+    }
+    a.params = c->pre_params; a.histeq = c->pre_histeq; a.status = d_status;
+    a.out = d_netin; a.out_prec = c->prec; a.H = lb.H; a.W = lb.W; a.top = lb.top; a.left = lb.left;
+    a.new_h = lb.new_h; a.new_w = lb.new_w;
+    const bool resize = (lb.new_h != th) || (lb.new_w != tw);
+    if (resize && (size_t)B * 3 * th * tw > c->pre_scratch_elems) return fail(c, CY_ERR_ARG, "resize scratch too small");
+    a.scratch = resize ? c->pre_scratch : nullptr;
+    HIPCHK(c, launch_preproc(a, s));
+    return CY_OK;
+}
+
+int cy_letterbox_pack(cy_ctx* c, const double* d_planes, int B, int h0, int w0, int imgsz, void* d_netin, void* stream) {
+    if (!c || !c->loaded) return fail(c, CY_ERR_STATE, "weights not loaded");
+    if (!d_planes || !d_netin || B < 1 || B > c->cfg.max_batch) return fail(c, CY_ERR_ARG, "bad arguments");
+    cy_letterbox lb;
+    if (cy_letterbox_geometry(h0, w0, imgsz, &lb)) return fail(c, CY_ERR_ARG, "bad image/imgsz");
+    if (lb.H > c->cfg.max_h || lb.W > c->cfg.max_w) return fail(c, CY_ERR_ARG, "letterboxed image exceeds max_h/max_w of the context");
+    PreArgs a{};
+    a.B = B; a.th = h0; a.tw = w0; a.scratch = const_cast<double*>(d_planes);
+    a.out = d_netin; a.out_prec = c->prec; a.H = lb.H; a.W = lb.W; a.top = lb.top; a.left = lb.left;
+    a.new_h = lb.new_h; a.new_w = lb.new_w;
+    HIPCHK(c, launch_letterbox_pack(a, (hipStream_t)stream));
+    return CY_OK;
+}
+
+int cy_decode_nms(cy_ctx* c, const float* d_pred, int B, int H, int W, int h0, int w0, float conf, float iou,
+                  float* d_det, int* d_det_anchor, int* d_count, void* stream) {
+    if (!c || !c->loaded) return fail(c, CY_ERR_STATE, "weights not loaded");
+    if (!d_pred || !d_det || !d_det_anchor || !d_count || B < 1 || B > c->cfg.max_batch) return fail(c, CY_ERR_ARG, "bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    DecodeArgs d{};
+    d.pred = d_pred; d.B = B; d.A = cy_num_anchors(H, W); d.nc = c->plan.nc; d.conf = conf;
+    for (int l = 0; l < 3; ++l) { d.lvl_h[l] = H >> (3 + l); d.lvl_w[l] = W >> (3 + l); }
+    d.cand = c->cand; d.cand_anchor = c->cand_anchor; d.cand_count = c->cand_count; d.cap = c->cap;
+    HIPCHK(c, hipMemsetAsync(c->cand_count, 0, B * sizeof(int), s));
+    HIPCHK(c, launch_decode(d, s));
+    NmsArgs n{};
+    n.cand = c->cand; n.cand_anchor = c->cand_anchor; n.cand_count = c->cand_count; n.cap = c->cap; n.B = B; n.iou = iou;
+    n.max_det = CY_MAX_DET;
+    // ultralytics scale_boxes: gain / pad from the letterboxed and original shapes
+    const double gain = std::fmin((double)H / h0, (double)W / w0);
+    n.gain = (float)gain;
+    n.padw = py_round_half_even((W - w0 * gain) / 2 - 0.1); n.padh = py_round_half_even((H - h0 * gain) / 2 - 0.1);
+    n.w0 = w0; n.h0 = h0;
+    n.det = d_det; n.det_anchor = d_det_anchor; n.det_count = d_count; n.keys = c->keys; n.mask = c->mask;
+    HIPCHK(c, launch_nms(n, s));
+    return CY_OK;
+}
+
+int cy_iou_merge(cy_ctx* c, const float* d_det, const int* d_count, int B, float score_thr, double soft, double hard,
+                 float* d_out, int* d_out_count, int* d_out_src, void* stream) {
+    if (!c || !c->loaded) return fail(c, CY_ERR_STATE, "weights not loaded");
+    if (!d_det || !d_count || !d_out || !d_out_count || B < 1 || B > c->cfg.max_batch) return fail(c, CY_ERR_ARG, "bad arguments");
+    MergeArgs m{};
+    m.det = d_det; m.det_count = d_count; m.B = B; m.max_det = CY_MAX_DET; m.score_thr = score_thr; m.soft = soft; m.hard = hard;
+    m.out = d_out; m.out_count = d_out_count; m.out_src = d_out_src ? d_out_src : c->out_src; m.err = c->merge_err;
+    HIPCHK(c, launch_iou_merge(m, (hipStream_t)stream));
+    return CY_OK;
+}
+
+int cy_detect_tiles(cy_ctx* c, const float* d_mosaic, int MH, int MW, const int* h_tiles, int B, int th, int tw, int imgsz,
+                    const cy_preproc_cfg* cfg, float conf, float iou, double soft, double hard,
+                    float* d_out, int* d_out_count, int* d_status, void* stream) {
+    if (!c || !c->loaded) return fail(c, CY_ERR_STATE, "weights not loaded");
+    cy_letterbox lb;
+    if (cy_letterbox_geometry(th, tw, imgsz, &lb)) return fail(c, CY_ERR_ARG, "bad tile/imgsz");
+    int rc = cy_preproc(c, d_mosaic, MH, MW, h_tiles, B, th, tw, imgsz, cfg, c->netin, d_status, stream);
+    if (rc) return rc;
+    rc = cy_forward(c, c->netin, B, lb.H, lb.W, c->pred, stream);
+    if (rc) return rc;
+    rc = cy_decode_nms(c, c->pred, B, lb.H, lb.W, th, tw, conf, iou, c->det, c->det_anchor, c->det_count, stream);
+    if (rc) return rc;
+    return cy_iou_merge(c, c->det, c->det_count, B, conf, soft, hard, d_out, d_out_count, nullptr, stream);
+}
+
+}  // extern "C"

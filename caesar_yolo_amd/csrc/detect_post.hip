@@ -1,0 +1,294 @@
+// Detection post-processing on device (gfx950): Detect/DFL decode + confidence filter, wavefront-scan NMS with the
+// letterbox undo, and the reference's per-tile IoU graph merge.
+//
+//   decode  : ultralytics Detect inference branch (DFL softmax-expectation, dist2bbox(xywh) * stride, sigmoid) and the
+//             candidate filter of non_max_suppression -- SURVEY.md Appendix A.1 steps 5-6
+//   nms     : torchvision.ops.nms semantics on class-offset boxes (+ cls*7680), IoU > thr (strict), stable score order,
+//             first 300 kept, then scale_boxes/clip_boxes -- Appendix A.1 steps 6-7
+//   merge   : Analyzer.process_detections (caesar_yolo/evaluation.py:252-346) with get_iou (caesar_yolo/utils.py:54-107)
+//             and Graph.connectedComponents (caesar_yolo/graph.py:2-41)
+//
+// All threshold comparisons are discontinuities, so the arithmetic is written operation by operation in the reference's
+// precision and order, with floating-point contraction disabled for this translation unit.
+#include "cy_kernels.h"
+#pragma clang fp contract(off)
+
+namespace cy {
+
+constexpr int MAXDET = 300;          // ultralytics max_det (CY_MAX_DET)
+constexpr int MAX_NMS = 30000;       // ultralytics max_nms
+constexpr float MAX_WH = 7680.0f;    // ultralytics max_wh (class offset)
+
+// ------------------------------------------------------------------------------------------------ decode
+__global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs a) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.A) return;
+    // anchor -> (level, y, x): levels are concatenated stride 8, 16, 32, each row-major
+    int lvl = 0, r = i;
+    const int n0 = a.lvl_h[0] * a.lvl_w[0], n1 = a.lvl_h[1] * a.lvl_w[1];
+    if (r >= n0) { r -= n0; lvl = 1; if (r >= n1) { r -= n1; lvl = 2; } }
+    const int gw = a.lvl_w[lvl];
+    const float ax = (float)(r % gw) + 0.5f, ay = (float)(r / gw) + 0.5f;
+    const float stride = (float)(8 << lvl);
+    const float* p = a.pred + ((size_t)b * a.A + i) * (64 + a.nc);
+    // class scores first: most anchors fail the confidence test and skip the DFL work
+    float best = -1.0f; int bj = 0;
+    for (int c = 0; c < a.nc; ++c) {
+        const float s = 1.0f / (1.0f + expf(-p[64 + c]));
+        if (s > best) { best = s; bj = c; }        // first maximum wins, as torch.max(1)
+    }
+    if (!(best > a.conf)) return;
+    float d[4];
+#pragma unroll
+    for (int side = 0; side < 4; ++side) {
+        const float* q = p + side * 16;
+        float m = q[0];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) m = fmaxf(m, q[k]);
+        float e[16], s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { e[k] = expf(q[k] - m); s += e[k]; }
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc += (e[k] / s) * (float)k;
+        d[side] = acc;
+    }
+    // dist2bbox(xywh=True) then * stride, then xywh2xyxy of non_max_suppression
+    const float x1 = ax - d[0], y1 = ay - d[1], x2 = ax + d[2], y2 = ay + d[3];
+    const float cx = ((x1 + x2) / 2.0f) * stride, cy_ = ((y1 + y2) / 2.0f) * stride;
+    const float w = (x2 - x1) * stride, h = (y2 - y1) * stride;
+    const float hw = w / 2.0f, hh = h / 2.0f;
+    const int slot = atomicAdd(a.cand_count + b, 1);
+    if (slot >= a.cap) return;
+    float* o = a.cand + ((size_t)b * a.cap + slot) * 6;
+    o[0] = cx - hw; o[1] = cy_ - hh; o[2] = cx + hw; o[3] = cy_ + hh; o[4] = best; o[5] = (float)bj;
+    a.cand_anchor[(size_t)b * a.cap + slot] = i;
+}
+
+hipError_t launch_decode(const DecodeArgs& a, hipStream_t s) {
+    if (a.A >= 65536 || a.cap >= 65536) return hipErrorInvalidValue;     // key packing below: 16 + 16 bits
+    hipLaunchKernelGGL(decode_kernel, dim3((a.A + 255) / 256, a.B), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ NMS
+// One 256-thread workgroup per tile.  (1) order candidates by (score desc, anchor asc) with a bitonic network on 64-bit
+// keys -- in LDS when they fit, else through L2; (2) wave 0 scans the ordered list 64 boxes at a time: every lane tests
+// its box against the boxes kept so far (<= 300, in LDS), then the 64 survivors are resolved against each other in
+// order with ballots; the scan stops at max_det kept boxes, which are exactly torchvision's keep[:max_det].
+constexpr int NMS_LDS_KEYS = 4096;
+
+__device__ __forceinline__ bool iou_gt(float ix1, float iy1, float ix2, float iy2, float iarea,
+                                       float jx1, float jy1, float jx2, float jy2, float jarea, float thr) {
+    const float xx1 = fmaxf(ix1, jx1), yy1 = fmaxf(iy1, jy1), xx2 = fminf(ix2, jx2), yy2 = fminf(iy2, jy2);
+    const float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
+    const float inter = w * h;
+    const float ovr = inter / (iarea + jarea - inter);
+    return ovr > thr;
+}
+
+__global__ __launch_bounds__(256) void nms_kernel(const NmsArgs a, int cap_pow2) {
+    __shared__ uint64_t lkeys[NMS_LDS_KEYS];
+    __shared__ float kx1[MAXDET], ky1[MAXDET], kx2[MAXDET], ky2[MAXDET], kar[MAXDET];
+    __shared__ int kslot[MAXDET];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    int n = a.cand_count[b];
+    if (n > a.cap) n = a.cap;
+    if (n == 0) { if (tid == 0) a.det_count[b] = 0; return; }
+    int np2 = 64;
+    while (np2 < n) np2 <<= 1;
+    uint64_t* keys = np2 <= NMS_LDS_KEYS ? lkeys : a.keys + (size_t)b * cap_pow2;
+    const float* cand = a.cand + (size_t)b * a.cap * 6;
+    const int* canch = a.cand_anchor + (size_t)b * a.cap;
+    for (int i = tid; i < np2; i += 256) {
+        uint64_t k = ~0ull;
+        if (i < n) {
+            const unsigned sb = __float_as_uint(cand[i * 6 + 4]);            // scores are positive: bit order = value order
+            k = ((uint64_t)(~sb) << 32) | ((uint64_t)(unsigned)canch[i] << 16) | (unsigned)i;
+        }
+        keys[i] = k;
+    }
+    __syncthreads();
+    for (int kk = 2; kk <= np2; kk <<= 1)
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < np2; i += 256) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const bool up = (i & kk) == 0;
+                    const uint64_t x = keys[i], y = keys[ixj];
+                    if ((x > y) == up) { keys[i] = y; keys[ixj] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    if (n > MAX_NMS) n = MAX_NMS;
+    if (tid >= 64) return;                              // the scan is one wavefront
+    const int lane = tid;
+    int nk = 0;
+    for (int base = 0; base < n && nk < a.max_det; base += 64) {
+        const int idx = base + lane;
+        const bool valid = idx < n;
+        int slot = 0;
+        float x1 = 0, y1 = 0, x2 = 0, y2 = 0, area = 0;
+        if (valid) {
+            slot = (int)(keys[idx] & 0xFFFFu);
+            const float* c = cand + slot * 6;
+            const float off = c[5] * MAX_WH;            // class-aware: boxes + cls * max_wh
+            x1 = c[0] + off; y1 = c[1] + off; x2 = c[2] + off; y2 = c[3] + off;
+            area = (x2 - x1) * (y2 - y1);
+        }
+        bool alive = valid;
+        for (int t = 0; t < nk; ++t) {
+            if (alive && iou_gt(kx1[t], ky1[t], kx2[t], ky2[t], kar[t], x1, y1, x2, y2, area, a.iou)) alive = false;
+            if ((t & 15) == 15 && __ballot(alive) == 0ull) break;
+        }
+        unsigned long long m = __ballot(alive);
+        while (m != 0ull && nk < a.max_det) {
+            const int j = __ffsll((long long)m) - 1;    // lowest alive lane = next kept box (wave-uniform)
+            const float jx1 = __shfl(x1, j), jy1 = __shfl(y1, j), jx2 = __shfl(x2, j), jy2 = __shfl(y2, j);
+            const float jar = __shfl(area, j);
+            const int jslot = __shfl(slot, j);
+            if (lane == 0) { kx1[nk] = jx1; ky1[nk] = jy1; kx2[nk] = jx2; ky2[nk] = jy2; kar[nk] = jar; kslot[nk] = jslot; }
+            ++nk;
+            if (lane > j && alive && iou_gt(jx1, jy1, jx2, jy2, jar, x1, y1, x2, y2, area, a.iou)) alive = false;
+            if (lane == j) alive = false;
+            m = __ballot(alive);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0xc07f);             // lgkmcnt(0): kept[] stores visible to the next round's reads
+    }
+    // ---- emit: undo the letterbox (scale_boxes + clip_boxes) on the un-offset boxes, in kept (= score) order
+    if (lane == 0) a.det_count[b] = nk;
+    for (int t = lane; t < nk; t += 64) {
+        const float* c = cand + kslot[t] * 6;
+        float bx1 = (c[0] - (float)a.padw) / a.gain, by1 = (c[1] - (float)a.padh) / a.gain;
+        float bx2 = (c[2] - (float)a.padw) / a.gain, by2 = (c[3] - (float)a.padh) / a.gain;
+        bx1 = fminf(fmaxf(bx1, 0.0f), (float)a.w0); bx2 = fminf(fmaxf(bx2, 0.0f), (float)a.w0);
+        by1 = fminf(fmaxf(by1, 0.0f), (float)a.h0); by2 = fminf(fmaxf(by2, 0.0f), (float)a.h0);
+        float* o = a.det + ((size_t)b * a.max_det + t) * 6;
+        o[0] = bx1; o[1] = by1; o[2] = bx2; o[3] = by2; o[4] = c[4]; o[5] = c[5];
+        a.det_anchor[(size_t)b * a.max_det + t] = canch[kslot[t]];
+    }
+}
+
+hipError_t launch_nms(const NmsArgs& a, hipStream_t s) {
+    if (a.max_det > MAXDET) return hipErrorInvalidValue;
+    int cp2 = 1;
+    while (cp2 < a.cap) cp2 <<= 1;
+    hipLaunchKernelGGL(nms_kernel, dim3(a.B), dim3(256), 0, s, a, cp2);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ IoU graph merge
+// One wavefront per tile, N <= 300 detections.  Pair tests are lane-parallel (one ballot fills 64 adjacency bits);
+// connected components are walked by lane 0 in exactly the reference's DFS preorder, because the survivor of a
+// component is the FIRST member in that order with the strictly largest score (evaluation.py:322-331).
+__global__ __launch_bounds__(64) void iou_merge_kernel(const MergeArgs a) {
+    constexpr int W64 = (MAXDET + 63) / 64;
+    __shared__ int sel[MAXDET];
+    __shared__ float bx[MAXDET][4];
+    __shared__ float sc[MAXDET];
+    __shared__ int cl[MAXDET];
+    __shared__ unsigned long long adj[MAXDET][W64];
+    __shared__ int stack[MAXDET];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    int nin = a.det_count[b];
+    if (nin > a.max_det) nin = a.max_det;
+    const float* det = a.det + (size_t)b * a.max_det * 6;
+    // ---- score re-filter (evaluation.py:282 drops score < thr), order preserved; degenerate boxes are dropped and
+    // counted (the reference would abort on get_iou's assert)
+    int n = 0, nerr = 0;
+    for (int base = 0; base < nin; base += 64) {
+        const int i = base + lane;
+        bool keep = false, bad = false;
+        if (i < nin) {
+            const float* d = det + i * 6;
+            keep = !(d[4] < a.score_thr);
+            bad = keep && !(d[0] < d[2] && d[1] < d[3]);
+            keep = keep && !bad;
+        }
+        const unsigned long long m = __ballot(keep);
+        nerr += __popcll(__ballot(bad));
+        if (keep) {
+            const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
+            const float* d = det + i * 6;
+            sel[pos] = i; bx[pos][0] = d[0]; bx[pos][1] = d[1]; bx[pos][2] = d[2]; bx[pos][3] = d[3];
+            sc[pos] = d[4]; cl[pos] = (int)d[5];
+        }
+        n += __popcll(m);
+    }
+    for (int i = lane; i < n * W64; i += 64) adj[i / W64][i % W64] = 0ull;
+    __syncthreads();
+    // ---- adjacency: mergeable = iou >= hard or (same class and iou >= soft); iou = f32 areas, f64 division
+    for (int i = 0; i < n - 1; ++i) {
+        const float ax1 = bx[i][0], ay1 = bx[i][1], ax2 = bx[i][2], ay2 = bx[i][3];
+        const float aarea = (ax2 - ax1) * (ay2 - ay1);
+        const int acl = cl[i];
+        for (int w = i / 64; w * 64 < n; ++w) {
+            const int j = w * 64 + lane;
+            bool e = false;
+            if (j > i && j < n) {
+                const float xl = fmaxf(ax1, bx[j][0]), yt = fmaxf(ay1, bx[j][1]);
+                const float xr = fminf(ax2, bx[j][2]), yb = fminf(ay2, bx[j][3]);
+                double iou = 0.0;
+                if (!(xr < xl || yb < yt)) {
+                    const float inter = (xr - xl) * (yb - yt);
+                    const float barea = (bx[j][2] - bx[j][0]) * (bx[j][3] - bx[j][1]);
+                    const float uni = aarea + barea - inter;
+                    iou = (double)inter / (double)uni;
+                }
+                e = (iou >= a.hard) || (acl == cl[j] && iou >= a.soft);
+                if (e) adj[j][i >> 6] |= 1ull << (i & 63);      // row j is owned by this lane in this round
+            }
+            const unsigned long long m = __ballot(e);
+            if (lane == 0 && m) adj[i][w] |= m;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    // ---- connected components in DFS preorder (graph.py:9-41), survivor = first strict maximum of the score
+    if (lane == 0) {
+        unsigned long long vis[W64];
+        for (int w = 0; w < W64; ++w) vis[w] = 0ull;
+        int nout = 0;
+        float* out = a.out + (size_t)b * a.max_det * 6;
+        int* osrc = a.out_src + (size_t)b * a.max_det;
+        for (int v0 = 0; v0 < n; ++v0) {
+            if ((vis[v0 >> 6] >> (v0 & 63)) & 1ull) continue;
+            float best = 0.0f; int ibest = -1;
+            int sp = 0;
+            stack[sp++] = v0;
+            vis[v0 >> 6] |= 1ull << (v0 & 63);
+            if (sc[v0] > best) { best = sc[v0]; ibest = v0; }
+            while (sp > 0) {
+                const int v = stack[sp - 1];
+                int u = -1;
+                for (int w = 0; w < W64 && u < 0; ++w) {
+                    const unsigned long long c = adj[v][w] & ~vis[w];
+                    if (c) u = w * 64 + __ffsll((long long)c) - 1;
+                }
+                if (u < 0) { --sp; continue; }
+                vis[u >> 6] |= 1ull << (u & 63);
+                if (sc[u] > best) { best = sc[u]; ibest = u; }
+                stack[sp++] = u;
+            }
+            if (ibest < 0) ibest = v0;          // all scores <= 0: the reference would index [-1]; keep the root instead
+            float* o = out + nout * 6;
+            o[0] = bx[ibest][0]; o[1] = bx[ibest][1]; o[2] = bx[ibest][2]; o[3] = bx[ibest][3];
+            o[4] = sc[ibest]; o[5] = (float)cl[ibest];
+            osrc[nout] = sel[ibest];
+            ++nout;
+        }
+        a.out_count[b] = nout;
+        a.err[b] = nerr;
+    }
+}
+
+hipError_t launch_iou_merge(const MergeArgs& a, hipStream_t s) {
+    if (a.max_det > MAXDET) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(iou_merge_kernel, dim3(a.B), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace cy

@@ -1,0 +1,241 @@
+"""`YOLO`-compatible detector object backed by the HIP library.
+
+Mirrors the slice of `ultralytics.YOLO` that the reference touches:
+  * construction with a weights path            scripts/run.py:347
+  * `.names` (dict class id -> label)           caesar_yolo/evaluation.py:46-47, :265
+  * `model(image, device=, imgsz=, conf=, iou=, **ignored)` returning an iterable of results whose
+    `.boxes.xyxy / .conf / .cls` support `.cpu().numpy()`      caesar_yolo/evaluation.py:181-193, :261-265
+plus the additive batched entry the tile scheduler uses (`detect_tiles`): B same-shape tiles cropped from an
+HBM-resident mosaic -> merged detections, everything on device.
+
+PyTorch is used only for device memory and streams; all arithmetic is in libcaesar_yolo_hip.so.  There is no CPU
+path: constructing a detector without a visible GPU, or without the built library, raises.
+"""
+import ctypes as C
+import os
+import numpy as np
+import torch
+
+from . import lib as L
+from . import weights as W
+
+
+def _dev_index(device):
+    if isinstance(device, int):
+        return device
+    s = str(device)
+    if s in ("", "cuda", "gpu"):
+        return torch.cuda.current_device()
+    if s.startswith("cuda:"):
+        return int(s.split(":")[1])
+    if s.isdigit():
+        return int(s)
+    if s == "cpu":
+        raise L.CyError("device='cpu' requested: this detector has no CPU path (use the reference for CPU runs)")
+    raise L.CyError("unknown device %r" % (device,))
+
+
+class HipDetector(object):
+    """One library context on one GPU.  Thin, explicit wrappers over the C-ABI stage entry points."""
+
+    def __init__(self, weights_path, device=0, precision="fp16", max_batch=64, max_imgsz=640, max_cand=0):
+        self.lib = L.load()
+        if not torch.cuda.is_available():
+            raise L.CyError("no GPU visible: the HIP detector cannot run (no CPU fallback exists)")
+        self.device = _dev_index(device)
+        self.tdev = torch.device("cuda", self.device)
+        self.precision = L.F16 if precision in ("fp16", "f16", "half", L.F16) else L.F32
+        self.dtype = torch.float16 if self.precision == L.F16 else torch.float32
+        self.max_batch = int(max_batch)
+        m = (int(max_imgsz) + 31) // 32 * 32
+        cfg = L.cy_config(self.precision, self.max_batch, m, m, int(max_cand))
+        self.ctx = C.c_void_p()
+        L.check(self.lib.cy_create(self.device, C.byref(cfg), C.byref(self.ctx)))
+        L.check(self.lib.cy_load_weights(self.ctx, os.fsencode(weights_path)), self.ctx)
+        nc = self.lib.cy_num_classes(self.ctx)
+        self.names = {i: self.lib.cy_class_name(self.ctx, i).decode() for i in range(nc)}
+        self.nc = nc
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.cy_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- helpers
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.tdev).cuda_stream)
+
+    @staticmethod
+    def _p(t):
+        return C.c_void_p(t.data_ptr())
+
+    def _chk(self, rc):
+        return L.check(rc, self.ctx)
+
+    # ---- stages
+    def mosaic_to_device(self, data, big_endian=None):
+        """Host fp32 image [H,W] (either byte order) -> resident device mosaic with read_fits value semantics."""
+        arr = np.asarray(data)
+        if arr.dtype.kind != "f" or arr.dtype.itemsize != 4:
+            arr = arr.astype("<f4")
+        if big_endian is None:
+            big_endian = arr.dtype.byteorder == ">"
+        raw = np.ascontiguousarray(arr).view(np.uint32).view(np.int32)
+        t = torch.from_numpy(raw.copy() if not raw.flags.writeable else raw).to(self.tdev).view(torch.float32)
+        self._chk(self.lib.cy_mosaic_prepare(self.ctx, self._p(t), t.numel(), int(bool(big_endian)), self._stream()))
+        return t
+
+    def preproc(self, mosaic, tiles_xy, th, tw, imgsz, cfg):
+        B = len(tiles_xy)
+        lb = L.letterbox(th, tw, imgsz)
+        netin = torch.empty((B, lb.H, lb.W, 4), dtype=self.dtype, device=self.tdev)
+        status = torch.empty((B,), dtype=torch.int32, device=self.tdev)
+        t = (C.c_int * (2 * B))(*[int(v) for xy in tiles_xy for v in xy])
+        self._chk(self.lib.cy_preproc(self.ctx, self._p(mosaic), mosaic.shape[0], mosaic.shape[1], t, B, th, tw, imgsz,
+                                      C.byref(cfg), self._p(netin), self._p(status), self._stream()))
+        return netin, status, lb
+
+    def preproc_params(self, B):
+        out = np.zeros((B, 3, L.CY_MAX_STAGES, 4), np.float64)
+        self._chk(self.lib.cy_preproc_params(self.ctx, out.ctypes.data_as(C.POINTER(C.c_double)), B))
+        return out
+
+    def letterbox_pack(self, planes, imgsz):
+        """planes: device float64 [B,3,h0,w0] (image channel order, [0,255])."""
+        B, _, h0, w0 = planes.shape
+        lb = L.letterbox(h0, w0, imgsz)
+        netin = torch.empty((B, lb.H, lb.W, 4), dtype=self.dtype, device=self.tdev)
+        self._chk(self.lib.cy_letterbox_pack(self.ctx, self._p(planes), B, h0, w0, imgsz, self._p(netin), self._stream()))
+        return netin, lb
+
+    def forward(self, netin):
+        B, H, Wd, _ = netin.shape
+        A = self.lib.cy_num_anchors(H, Wd)
+        pred = torch.empty((B, A, 64 + self.nc), dtype=torch.float32, device=self.tdev)
+        self._chk(self.lib.cy_forward(self.ctx, self._p(netin), B, H, Wd, self._p(pred), self._stream()))
+        return pred
+
+    def read_conv(self, name, shape_hint_elems):
+        buf = np.zeros(shape_hint_elems, np.float32)
+        dims = (C.c_int * 4)()
+        self._chk(self.lib.cy_debug_read_conv(self.ctx, name.encode(), buf.ctypes.data_as(C.POINTER(C.c_float)),
+                                              buf.size, dims))
+        d = tuple(dims)
+        return buf[:int(np.prod(d))].reshape(d)
+
+    def decode_nms(self, pred, H, Wd, h0, w0, conf, iou):
+        B = pred.shape[0]
+        det = torch.zeros((B, L.CY_MAX_DET, 6), dtype=torch.float32, device=self.tdev)
+        anch = torch.zeros((B, L.CY_MAX_DET), dtype=torch.int32, device=self.tdev)
+        cnt = torch.zeros((B,), dtype=torch.int32, device=self.tdev)
+        self._chk(self.lib.cy_decode_nms(self.ctx, self._p(pred), B, H, Wd, h0, w0, conf, iou, self._p(det),
+                                         self._p(anch), self._p(cnt), self._stream()))
+        return det, anch, cnt
+
+    def iou_merge(self, det, cnt, score_thr, soft, hard):
+        B = det.shape[0]
+        out = torch.zeros_like(det)
+        ocnt = torch.zeros((B,), dtype=torch.int32, device=self.tdev)
+        osrc = torch.zeros((B, L.CY_MAX_DET), dtype=torch.int32, device=self.tdev)
+        self._chk(self.lib.cy_iou_merge(self.ctx, self._p(det), self._p(cnt), B, score_thr, soft, hard, self._p(out),
+                                        self._p(ocnt), self._p(osrc), self._stream()))
+        return out, ocnt, osrc
+
+    def detect_tiles(self, mosaic, tiles_xy, th, tw, imgsz, cfg, conf, iou, soft, hard, out=None):
+        """Whole per-tile path for B same-shape tiles.  Returns (det [B,300,6], count [B], status [B]) on device."""
+        B = len(tiles_xy)
+        if out is None:
+            det = torch.empty((B, L.CY_MAX_DET, 6), dtype=torch.float32, device=self.tdev)
+            cnt = torch.empty((B,), dtype=torch.int32, device=self.tdev)
+            status = torch.empty((B,), dtype=torch.int32, device=self.tdev)
+        else:
+            det, cnt, status = out
+        t = (C.c_int * (2 * B))(*[int(v) for xy in tiles_xy for v in xy])
+        self._chk(self.lib.cy_detect_tiles(self.ctx, self._p(mosaic), mosaic.shape[0], mosaic.shape[1], t, B, th, tw,
+                                           imgsz, C.byref(cfg), conf, iou, soft, hard, self._p(det), self._p(cnt),
+                                           self._p(status), self._stream()))
+        return det, cnt, status
+
+    def conv_bn_silu(self, x_nhwc, w, b, k, s, act=True, res=None):
+        B, Hi, Wi, Cin = x_nhwc.shape
+        Cout = w.shape[0]
+        pad = k // 2
+        Ho, Wo = (Hi + 2 * pad - k) // s + 1, (Wi + 2 * pad - k) // s + 1
+        out = torch.empty((B, Ho, Wo, Cout), dtype=self.dtype, device=self.tdev)
+        w = np.ascontiguousarray(w, np.float32)
+        b = np.ascontiguousarray(b, np.float32)
+        self._chk(self.lib.cy_conv_bn_silu(self.ctx, self._p(x_nhwc), B, Hi, Wi, Cin,
+                                           w.ctypes.data_as(C.POINTER(C.c_float)), b.ctypes.data_as(C.POINTER(C.c_float)),
+                                           Cout, k, s, int(act), self._p(res) if res is not None else None,
+                                           self._p(out), self._stream()))
+        return out
+
+
+class _Boxes(object):
+    def __init__(self, det):
+        self.xyxy, self.conf, self.cls = det[:, :4], det[:, 4], det[:, 5]
+
+
+class Results(object):
+    def __init__(self, det):
+        self.boxes = _Boxes(det)
+
+
+class YOLO(object):
+    """Drop-in for `ultralytics.YOLO(weights)` on the reference's detect path.
+
+    `weights` is a CYW1 file (caesar_yolo_amd.weights); the string "seeded:<scale>:<nc>[:seed]" builds the
+    deterministic random-init checkpoint used by the tests and the benchmark (no trained weights ship with the
+    reference)."""
+
+    def __init__(self, weights, precision="fp16", max_batch=64, max_imgsz=640, device=None):
+        self._wpath = self._resolve(weights)
+        self._kw = dict(precision=precision, max_batch=max_batch, max_imgsz=max_imgsz)
+        self._det = None
+        self._dev = device
+        scale, names, _, _ = W.read_cyw_header(self._wpath)
+        self.names = names
+        self.scale = scale
+
+    @staticmethod
+    def _resolve(weights):
+        if isinstance(weights, str) and weights.startswith("seeded:"):
+            parts = weights.split(":")
+            scale, nc = parts[1], int(parts[2])
+            seed = int(parts[3]) if len(parts) > 3 else 20260104
+            cache = os.environ.get("CAESAR_YOLO_CACHE", os.path.join(os.path.expanduser("~"), ".cache", "caesar_yolo_amd"))
+            os.makedirs(cache, exist_ok=True)
+            path = os.path.join(cache, "seeded_%s_nc%d_%d.cyw" % (scale, nc, seed))
+            if not os.path.exists(path):
+                tmp = path + ".%d.tmp" % os.getpid()
+                W.make_seeded_file(tmp, scale, nc, seed)
+                os.replace(tmp, path)
+            return path
+        if not os.path.isfile(weights):
+            raise FileNotFoundError(weights)
+        return weights
+
+    def engine(self, device=None):
+        if self._det is None:
+            dev = device if device is not None else (self._dev if self._dev is not None else
+                                                     int(os.environ.get("LOCAL_RANK", "0")))
+            self._det = HipDetector(self._wpath, device=dev, **self._kw)
+        return self._det
+
+    def __call__(self, image, device=None, imgsz=640, conf=0.25, iou=0.7, **ignored):
+        det = self.engine(device)
+        img = np.asarray(image, dtype=np.float64)
+        if img.ndim != 3 or img.shape[2] != 3:
+            raise ValueError("expected an (H,W,3) image")
+        planes = torch.from_numpy(np.ascontiguousarray(img.transpose(2, 0, 1))[None]).to(det.tdev)
+        netin, lb = det.letterbox_pack(planes, int(imgsz))
+        pred = det.forward(netin)
+        d, _, cnt = det.decode_nms(pred, lb.H, lb.W, img.shape[0], img.shape[1], float(conf), float(iou))
+        n = int(cnt[0].item())
+        return [Results(d[0, :n])]

@@ -177,3 +177,18 @@ def make_seeded_file(path, scale="l", nc=5, seed=20260104, names=None):
     ck = seeded_checkpoint(scale, nc, seed)
     write_cyw(path, fold(ck, scale, nc), names, scale)
     return path
+
+
+def read_cyw_header(path):
+    """-> (scale, names dict, nc, nconv) without touching the tensor payload."""
+    with open(path, "rb") as fp:
+        head = fp.read(24)
+        if head[:4] != b"CYW1":
+            raise ValueError("%s: not a CYW1 weight file" % path)
+        scale = head[8:12].rstrip(b"\0").decode()
+        nc, nconv, nnames = struct.unpack_from("<III", head, 12)
+        names = {}
+        for i in range(nnames):
+            n, = struct.unpack("<I", fp.read(4))
+            names[i] = fp.read((n + 3) // 4 * 4)[:n].decode()
+    return scale, names, nc, nconv

@@ -1,0 +1,137 @@
+/* caesar_yolo_hip.h -- C-ABI of the MI355X-native tiled-YOLO detect path (libcaesar_yolo_hip.so, gfx950).
+ *
+ * Drop-in boundary for the one hot path of SKA-INAF/caesar-yolo: everything `Analyzer.predict` does between
+ * receiving a tile and handing back merged boxes.  Citations are reference files (relative to the reference
+ * checkout) whose behaviour each entry point replaces.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative cy_status; nothing throws across the boundary
+ *     (the reference catches any exception from the model call and skips the tile: caesar_yolo/evaluation.py:194-196,
+ *     caesar_yolo/inference.py:615-618); `cy_last_error` gives the text;
+ *   - `d_*` pointers are DEVICE pointers owned by the caller (e.g. torch tensors' data_ptr()), `h_*` are host
+ *     pointers; `stream` is a hipStream_t passed as void* (NULL = default stream); all launches are asynchronous;
+ *   - one context per GPU; a context is not thread-safe; no allocation happens after cy_load_weights.
+ */
+#ifndef CAESAR_YOLO_HIP_H
+#define CAESAR_YOLO_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cy_ctx cy_ctx;
+
+enum cy_status { CY_OK = 0, CY_ERR_ARG = -1, CY_ERR_HIP = -2, CY_ERR_IO = -3, CY_ERR_STATE = -4, CY_ERR_UNSUPPORTED = -5 };
+enum cy_precision { CY_F16 = 0, CY_F32 = 1 };   /* CY_F16: fp16 operands, fp32 accumulate (fast); CY_F32: exact fp32 (parity) */
+
+#define CY_MAX_DET 300        /* ultralytics max_det */
+#define CY_DET_STRIDE 6       /* x1,y1,x2,y2,score,class */
+#define CY_MAX_STAGES 8
+
+typedef struct cy_config {
+    int precision;            /* cy_precision */
+    int max_batch;            /* tiles per launch the workspace is sized for */
+    int max_h, max_w;         /* largest letterboxed network input (multiple of 32) */
+    int max_cand;             /* candidate capacity per tile before NMS (<= 30000 = ultralytics max_nms); 0 -> 8192 */
+} cy_config;
+
+/* Preprocessing program: the CLI-fixed stage order of scripts/run.py:272-302, one op list per output channel.
+ * ops follow caesar_yolo/preprocessing.py: BKG :591-658, SHIFT :664-717, CLIP :723-771, ZSCALE :934-971,
+ * HISTEQ :977-1012, MINMAX :75-111.  Chan3Trasformer (:1020-1072) = three different programs. */
+enum cy_pre_op { CY_OP_BKG = 1, CY_OP_SHIFT = 2, CY_OP_CLIP = 3, CY_OP_ZSCALE = 4, CY_OP_HISTEQ = 5, CY_OP_MINMAX = 6 };
+typedef struct cy_pre_stage {
+    int op;
+    double p0, p1, p2;        /* BKG: sigma, mask_fract | SHIFT: sigma | CLIP: sigma_low, sigma_up | ZSCALE: contrast | MINMAX: norm_min, norm_max */
+    int flag;                 /* BKG: use_mask_box */
+} cy_pre_stage;
+typedef struct cy_pre_program { int n; cy_pre_stage st[CY_MAX_STAGES]; } cy_pre_program;
+typedef struct cy_preproc_cfg {
+    int nprog;                /* 0: no preprocessing (raw pixel values go to the network, as without --preprocessing);
+                                 1: one program, result replicated to 3 channels; 3: one program per channel */
+    cy_pre_program prog[3];
+} cy_preproc_cfg;
+
+typedef struct cy_conv_desc { char name[48]; int cin, cout, k, s, act; } cy_conv_desc;
+
+typedef struct cy_letterbox {  /* ultralytics LetterBox geometry for an (h0,w0) image at imgsz */
+    int new_h, new_w, top, left, H, W;
+} cy_letterbox;
+
+/* ---- lifetime -------------------------------------------------------------------------------- */
+/* replaces `model = YOLO(weights_path)` (scripts/run.py:347) + device selection (caesar_yolo/inference.py:205-217) */
+int cy_create(int device, const cy_config* cfg, cy_ctx** out);
+int cy_destroy(cy_ctx* ctx);
+const char* cy_last_error(const cy_ctx* ctx);
+int cy_load_weights(cy_ctx* ctx, const char* path);                 /* CYW1 file (caesar_yolo_amd/weights.py) */
+int cy_load_weights_mem(cy_ctx* ctx, const void* buf, size_t nbytes);
+int cy_num_classes(const cy_ctx* ctx);                               /* len(model.names), caesar_yolo/evaluation.py:46-47 */
+const char* cy_class_name(const cy_ctx* ctx, int i);
+
+/* ---- host-only helpers (no GPU needed) ------------------------------------------------------- */
+int cy_plan_num_convs(char scale, int nc);
+int cy_plan_conv_desc(char scale, int nc, int idx, cy_conv_desc* out);
+int cy_letterbox_geometry(int h0, int w0, int imgsz, cy_letterbox* out);
+int cy_num_anchors(int H, int W);
+size_t cy_pred_elems(const cy_ctx* ctx, int B, int H, int W);        /* floats in the raw head output [B][A][64+nc] */
+
+/* ---- stages ---------------------------------------------------------------------------------- */
+/* utils.read_fits / read_fits_crop value semantics (caesar_yolo/utils.py:219, :394): big-endian FITS floats ->
+ * native, non-finite -> 0, in place on the HBM-resident mosaic */
+int cy_mosaic_prepare(cy_ctx* ctx, float* d_data, size_t n, int big_endian, void* stream);
+
+/* Analyzer.predict steps evaluation.py:146-176 for B tiles of one shape (th x tw) cropped from the resident mosaic:
+ * 3-channel cube, DataPreprocessor pipeline, None / constant-row rejection, then the model's own LetterBox + BGR
+ * flip + /255.  h_tiles: B x {x0, y0} tile origins in mosaic pixels.
+ * d_netin: [B][H][W][4] (fp16 or fp32 per context precision); d_status[B]: 0 ok, 1 pipeline returned None, 2 row check */
+int cy_preproc(cy_ctx* ctx, const float* d_mosaic, int MH, int MW, const int* h_tiles, int B, int th, int tw,
+               int imgsz, const cy_preproc_cfg* cfg, void* d_netin, int* d_status, void* stream);
+/* witness for parity tests: solved per-stage parameters of the last cy_preproc call, [B][3][CY_MAX_STAGES][4] doubles */
+int cy_preproc_params(cy_ctx* ctx, double* h_out, int B);
+
+/* the model's own input handling for caller-supplied images (the `model(ndarray)` surface, evaluation.py:181-193):
+ * d_planes [B][3][h0][w0] float64 (image channel order, nominal range [0,255]) -> LetterBox + flip + /255 -> d_netin */
+int cy_letterbox_pack(cy_ctx* ctx, const double* d_planes, int B, int h0, int w0, int imgsz, void* d_netin, void* stream);
+
+/* DetectionModel.forward: d_netin [B][H][W][4] -> d_pred [B][A][64+nc] fp32 raw head output */
+int cy_forward(cy_ctx* ctx, const void* d_netin, int B, int H, int W, float* d_pred, void* stream);
+/* copy the output of one named convolution of the last cy_forward to host as fp32 [B][C][Ho][Wo] (test hook) */
+int cy_debug_read_conv(cy_ctx* ctx, const char* conv_name, float* h_out, size_t cap_elems, int* dims4);
+
+/* Detect decode + non_max_suppression + scale_boxes:
+ * d_det [B][300][6], d_det_anchor [B][300] (anchor index of each kept box), d_count [B] */
+int cy_decode_nms(cy_ctx* ctx, const float* d_pred, int B, int H, int W, int h0, int w0, float conf, float iou,
+                  float* d_det, int* d_det_anchor, int* d_count, void* stream);
+
+/* Analyzer.process_detections (caesar_yolo/evaluation.py:252-346): score re-filter, IoU graph, connected components,
+ * best score per component.  d_out [B][300][6], d_out_count [B], d_out_src [B][300] = row of d_det kept */
+int cy_iou_merge(cy_ctx* ctx, const float* d_det, const int* d_count, int B, float score_thr, double thr_soft,
+                 double thr_hard, float* d_out, int* d_out_count, int* d_out_src, void* stream);
+
+/* the whole per-tile path for B same-shape tiles; status/det/count as above (merged detections in tile pixels) */
+int cy_detect_tiles(cy_ctx* ctx, const float* d_mosaic, int MH, int MW, const int* h_tiles, int B, int th, int tw,
+                    int imgsz, const cy_preproc_cfg* cfg, float conf, float iou, double thr_soft, double thr_hard,
+                    float* d_out, int* d_out_count, int* d_status, void* stream);
+
+/* single fused Conv+bias+SiLU layer on caller tensors (kernel-level parity tests).
+ * d_in [B][Hi][Wi][Cin], d_out [B][Ho][Wo][Cout] in the context precision; h_w [Cout][Cin][k][k], h_b [Cout] fp32;
+ * d_res optional residual [B][Ho][Wo][Cout] */
+int cy_conv_bn_silu(cy_ctx* ctx, const void* d_in, int B, int Hi, int Wi, int Cin, const float* h_w, const float* h_b,
+                    int Cout, int k, int s, int act, const void* d_res, void* d_out, void* stream);
+
+/* ---- catalog records and cross-tile merge (host code, no GPU) --------------------------------- */
+/* Analyzer.make_json_results (caesar_yolo/evaluation.py:418-469: int() truncation, tile-local edge rule, tile origin)
+ * followed by SFinder.find_sources_at_edge (caesar_yolo/inference.py:663-726).
+ * det: n x 6 floats {x1,y1,x2,y2,score,class} in TILE pixels, grouped by tile in ascending tile order;
+ * det_tile: n tile ids; tiles: T x 4 ints {xmin, xmax_excl, ymin, ymax_excl} (utils.generate_tiles order);
+ * rec: n x 8 doubles {x1,y1,x2,y2,score,class_id,tile_id,edge}, edge = 0 | 1 (tile-local rule only, int in the
+ * reference JSON) | 2 (set True by find_sources_at_edge) */
+int cy_make_tile_records(const float* det, const int* det_tile, int n, const int* tiles, int T, double* rec);
+/* SFinder.merge_edge_sources (caesar_yolo/inference.py:731-931) on those records.
+ * out: up to n x 8 doubles {x1,y1,x2,y2,score,class_id,edge,merged}; returns the number of output sources (>= 0) */
+int cy_merge_edge_sources(const double* rec, int n, const int* tiles, int T, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

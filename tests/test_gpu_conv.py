@@ -1,0 +1,56 @@
+"""Kernel-level parity: the fused conv implicit-GEMM (csrc/conv_igemm.hip) against a plain PyTorch fp32 reference of
+the same op (F.conv2d + bias + SiLU + residual), through the C-ABI entry cy_conv_bn_silu.
+Tolerances: f32 path (exact-fp32 MFMA) 2e-5 relative to the output scale; f16 path (fp16 operands, fp32 accumulate)
+is compared on fp16-rounded inputs/weights with 4e-3 relative to the output scale (one fp16 rounding of the result)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+from gpu_common import detector
+
+pytestmark = pytest.mark.gpu
+
+CASES = [  # B, H, W, Cin, Cout, k, s, act, residual
+    (2, 32, 32, 64, 64, 3, 1, True, False),
+    (3, 20, 24, 128, 128, 3, 1, True, True),
+    (2, 32, 32, 64, 128, 3, 2, True, False),
+    (2, 16, 16, 256, 512, 1, 1, True, False),
+    (1, 8, 8, 320, 128, 1, 1, True, False),
+    (2, 16, 16, 64, 5, 1, 1, False, False),
+    (1, 9, 11, 72, 40, 3, 1, True, True),
+    (1, 64, 64, 64, 64, 3, 1, True, True),
+    (4, 16, 16, 512, 256, 3, 1, True, False),
+    (1, 5, 7, 8, 16, 3, 2, True, False),
+]
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+@pytest.mark.parametrize("case", CASES)
+def test_conv_bn_silu(prec, case):
+    B, H, W, Cin, Cout, k, s, act, use_res = case
+    det = detector(prec)
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn((B, Cin, H, W), generator=g)
+    w = torch.randn((Cout, Cin, k, k), generator=g) / (Cin * k * k) ** 0.5
+    b = torch.randn((Cout,), generator=g) * 0.1
+    if prec == "fp16":
+        x, w = x.half().float(), w.half().float()
+    y = F.conv2d(x, w, b, stride=s, padding=k // 2)
+    if act:
+        y = F.silu(y)
+    res = None
+    if use_res:
+        res = torch.randn(y.shape, generator=g)
+        if prec == "fp16":
+            res = res.half().float()
+        y = y + res
+    xd = x.permute(0, 2, 3, 1).contiguous().to(det.dtype).cuda()
+    rd = res.permute(0, 2, 3, 1).contiguous().to(det.dtype).cuda() if use_res else None
+    out = det.conv_bn_silu(xd, w.numpy(), b.numpy(), k, s, act, rd)
+    torch.cuda.synchronize()
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    assert got.shape == y.shape
+    scale = float(y.abs().max())
+    tol = (2e-5 if prec == "fp32" else 4e-3) * max(scale, 1.0)
+    err = float((got - y).abs().max())
+    assert err <= tol, "max abs err %.3e > %.3e (scale %.2f)" % (err, tol, scale)

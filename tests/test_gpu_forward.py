@@ -1,0 +1,67 @@
+"""Network parity: cy_forward (the whole YOLOv8l graph on HIP kernels) against the torch-CPU fp32 oracle on the same
+seeded weights and the same preprocessed tile.  f32 context: raw head output within 2e-4 (abs, logits are O(1-10));
+intermediate conv outputs within 1e-4 of their scale.  f16 context: within 6e-2 (fp16 operands through 100+ layers)."""
+import os
+import numpy as np
+import pytest
+import torch
+from gpu_common import detector, oracle_model, netin_from_chw, ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _tile(name, h=None, w=None):
+    from oracle import preprocessing_ref as P
+    g = np.load(os.path.join(ROOT, "tests/golden/preproc.npz"))
+    img = g["in/" + name]
+    if h:
+        img = img[:h, :w]
+    dp = P.build_pipeline([("zscale", dict(contrasts=[0.25] * 3)), ("minmax", dict(norm_min=0, norm_max=255))])
+    return dp(P.to_cube(img))
+
+
+def _oracle_forward(images, imgsz):
+    from oracle import yolov8_ref as Y
+    m = oracle_model()
+    xs = [Y.preprocess(im, imgsz)[0] for im in images]
+    x = torch.cat(xs, 0)
+    m.net.taps = {}
+    with torch.no_grad():
+        raw = m.net.forward(x)
+    return x, raw.permute(0, 2, 1).contiguous(), m.net.taps
+
+
+TAPS = ["model.0", "model.1", "model.2.cv1", "model.2.m.0.cv1", "model.2.m.0.cv2", "model.2.cv2", "model.4.cv2",
+        "model.6.cv2", "model.8.cv2", "model.9.cv1", "model.9.cv2", "model.12.cv1", "model.12.cv2", "model.15.cv1",
+        "model.15.cv2", "model.16", "model.18.cv2", "model.19", "model.21.cv2", "model.22.cv2.0.1", "model.22.cv3.2.1"]
+
+
+@pytest.mark.parametrize("prec,tol_raw,tol_tap", [("fp32", 2e-4, 1e-4), ("fp16", 6e-2, 3e-2)])
+def test_forward_matches_oracle(prec, tol_raw, tol_tap):
+    det = detector(prec)
+    imgs = [_tile("big512", 256, 256), _tile("big512", 256, 256)[::-1].copy()]
+    x, raw, taps = _oracle_forward(imgs, 256)
+    pred = det.forward(netin_from_chw(x, det.dtype))
+    torch.cuda.synchronize()
+    for name in TAPS:
+        ref = taps[name]
+        got = torch.from_numpy(det.read_conv(name, ref.numel()))
+        assert tuple(got.shape) == tuple(ref.shape), name
+        sc = max(float(ref.abs().max()), 1.0)
+        err = float((got - ref).abs().max())
+        assert err <= tol_tap * sc, "%s: max abs err %.3e (scale %.2f)" % (name, err, sc)
+    err = float((pred.cpu() - raw).abs().max())
+    assert err <= tol_raw * max(1.0, float(raw.abs().max())), "raw head output: max abs err %.3e" % err
+
+
+def test_forward_ragged_letterboxed_shape_fp32():
+    """394-wide edge tiles of the 16k mosaic letterbox to 416x512: non-square grids, 3 batch entries."""
+    det = detector("fp32")
+    base = _tile("big512")
+    imgs = [base[:512, :394].copy(), base[:512, 100:494].copy(), base[:512, 118:512].copy()]
+    x, raw, _ = _oracle_forward(imgs, 512)
+    assert tuple(x.shape[2:]) == (512, 416)
+    pred = det.forward(netin_from_chw(x, det.dtype))
+    torch.cuda.synchronize()
+    err = float((pred.cpu() - raw).abs().max())
+    assert err <= 2e-4 * max(1.0, float(raw.abs().max())), err

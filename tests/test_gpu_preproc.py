@@ -1,0 +1,134 @@
+"""Preprocessing parity through the C-ABI: cy_preproc (statistics + apply + letterbox/pack, csrc/cy_preproc.hip) against
+the numpy oracle, whose outputs are themselves pinned to vectors captured from the imported reference.
+Solved statistics (zscale limits, sigma-clip bounds, ...) agree to 1e-11 relative; the packed fp32 network input agrees
+to 1 fp32 ulp of the /255 value (2e-7 absolute); the zero mask is identical."""
+import os
+import numpy as np
+import pytest
+import torch
+from gpu_common import detector, ROOT
+from caesar_yolo_amd import preprocessing as PP
+from caesar_yolo_amd import lib as L
+
+pytestmark = pytest.mark.gpu
+
+PIPES = {
+    "zscale_minmax": lambda M: [M.ZScaleTransformer(contrasts=[0.25] * 3), M.MinMaxNormalizer(norm_min=0, norm_max=255)],
+    "full": lambda M: [M.BkgSubtractor(sigma=3), M.SigmaClipShifter(sigma=1), M.SigmaClipper(sigma_low=10, sigma_up=10),
+                       M.ZScaleTransformer(contrasts=[0.25] * 3), M.MinMaxNormalizer(norm_min=0, norm_max=255)],
+    "chan3_minmax": lambda M: [M.ChanResizer(nchans=3), M.Chan3Trasformer(sigma_clip_baseline=0, sigma_clip_low=10,
+                                                                          sigma_clip_up=10, zscale_contrast=0.25),
+                               M.MinMaxNormalizer(norm_min=0, norm_max=255)],
+    "bkg_box": lambda M: [M.BkgSubtractor(sigma=3, use_mask_box=True, mask_fract=0.7)],
+    "clip_1_3": lambda M: [M.SigmaClipper(sigma_low=1, sigma_up=3)],
+    "minmax": lambda M: [M.MinMaxNormalizer(norm_min=0, norm_max=255)],
+    "zscale_c40": lambda M: [M.ZScaleTransformer(contrasts=[0.4] * 3)],
+}
+ORACLE = {
+    "zscale_minmax": [("zscale", dict(contrasts=[0.25] * 3)), ("minmax", dict(norm_min=0, norm_max=255))],
+    "full": [("bkg", dict(sigma=3)), ("shift", dict(sigma=1)), ("clip", dict(sigma_low=10, sigma_up=10)),
+             ("zscale", dict(contrasts=[0.25] * 3)), ("minmax", dict(norm_min=0, norm_max=255))],
+    "chan3_minmax": [("chanresize", dict(nchans=3)), ("chan3", dict(sigma_clip_baseline=0, sigma_clip_low=10,
+                                                                   sigma_clip_up=10, zscale_contrast=0.25)),
+                     ("minmax", dict(norm_min=0, norm_max=255))],
+    "bkg_box": [("bkg", dict(sigma=3, use_mask_box=True, mask_fract=0.7))],
+    "clip_1_3": [("clip", dict(sigma_low=1, sigma_up=3))],
+    "minmax": [("minmax", dict(norm_min=0, norm_max=255))],
+    "zscale_c40": [("zscale", dict(contrasts=[0.4] * 3))],
+}
+
+
+def _mosaic(det, tiles):
+    """Lay the test tiles side by side in one resident mosaic (with a border so origins are non-trivial)."""
+    h = max(t.shape[0] for t in tiles) + 7
+    w = sum(t.shape[1] for t in tiles) + 5 * (len(tiles) + 1)
+    m = np.full((h, w), np.nan, np.float32)          # NaN background: exercises non-finite -> 0 on ingest
+    xy, x = [], 5
+    for t in tiles:
+        m[3:3 + t.shape[0], x:x + t.shape[1]] = t
+        xy.append((x, 3))
+        x += t.shape[1] + 5
+    return det.mosaic_to_device(m.astype(">f4")), xy      # big-endian like a FITS payload
+
+
+@pytest.mark.parametrize("pname", sorted(PIPES))
+@pytest.mark.parametrize("iname", ["galaxy", "syn192", "rag", "dense"])
+def test_preproc_matches_oracle(pname, iname):
+    from oracle import preprocessing_ref as P
+    from oracle import yolov8_ref as Y
+    det = detector("fp32", max_imgsz=640)
+    g = np.load(os.path.join(ROOT, "tests/golden/preproc.npz"))
+    img = g["in/" + iname]
+    th, tw = img.shape
+    imgsz = 256
+    mosaic, xy = _mosaic(det, [img, img[::-1].copy()])
+    cfg = PP.DataPreprocessor(PIPES[pname](PP)).program()
+    netin, status, lb = det.preproc(mosaic, xy, th, tw, imgsz, cfg)
+    torch.cuda.synchronize()
+    assert status.cpu().tolist() == [0, 0]
+    for b, src in enumerate([img, img[::-1].copy()]):
+        ref_img = P.build_pipeline(ORACLE[pname])(P.to_cube(src))
+        if b == 0 and not pname.startswith("chan3"):
+            # the oracle itself is pinned to the reference's output for this case
+            np.testing.assert_allclose(ref_img[:, :, 0], g["out/%s/%s" % (iname, pname)], rtol=1e-11, atol=1e-13)
+        x, hw = Y.preprocess(ref_img, imgsz)                       # [1,3,H,W] fp32, flipped, /255
+        assert hw == (lb.H, lb.W)
+        got = netin[b].float().cpu().numpy()                       # [H,W,4]
+        ref = x[0].permute(1, 2, 0).numpy()
+        assert np.all(got[..., 3] == 0)
+        if lb.new_h == th and lb.new_w == tw:
+            assert np.array_equal(got[..., :3] == 0, ref == 0)
+            np.testing.assert_allclose(got[..., :3], ref, rtol=0, atol=2e-7)
+        else:
+            np.testing.assert_allclose(got[..., :3], ref, rtol=0, atol=5e-7)
+
+
+def test_solved_statistics_match_reference_stats():
+    det = detector("fp32", max_imgsz=640)
+    g = np.load(os.path.join(ROOT, "tests/golden/preproc.npz"))
+    for iname in ["galaxy", "syn192", "rag", "dense", "big512"]:
+        img = g["in/" + iname]
+        th, tw = img.shape
+        mosaic, xy = _mosaic(det, [img])
+        cfg = PP.DataPreprocessor([PP.ZScaleTransformer([0.25] * 3)]).program()
+        det.preproc(mosaic, xy, th, tw, 640, cfg)
+        p = det.preproc_params(1)[0, 0]
+        np.testing.assert_allclose(p[0, :2], g["stats/%s/zscale_0.25" % iname], rtol=1e-11)
+        cfg = PP.DataPreprocessor([PP.SigmaClipper(10, 10)]).program()
+        det.preproc(mosaic, xy, th, tw, 640, cfg)
+        p = det.preproc_params(1)[0, 0]
+        np.testing.assert_allclose(p[0, :2], g["stats/%s/sigclip_bounds_10_10" % iname], rtol=1e-11)
+        cfg = PP.DataPreprocessor([PP.BkgSubtractor(sigma=3)]).program()
+        det.preproc(mosaic, xy, th, tw, 640, cfg)
+        p = det.preproc_params(1)[0, 0]
+        np.testing.assert_allclose(p[0, 0], g["stats/%s/sigstats_3" % iname][0], rtol=1e-10)
+
+
+def test_tile_rejection_status():
+    """All-zero tile -> MinMaxNormalizer returns None (status 1); constant first rows -> Analyzer's row check (status 2)."""
+    det = detector("fp32", max_imgsz=640)
+    g = np.load(os.path.join(ROOT, "tests/golden/preproc.npz"))
+    img = g["in/syn192"].copy()
+    z = np.zeros_like(img)
+    q = img.copy()
+    q[1, :] = 0.0
+    ok5 = img.copy()
+    ok5[5, :] = 0.0
+    mosaic, xy = _mosaic(det, [img, z, q, ok5])
+    cfg = PP.DataPreprocessor(PIPES["zscale_minmax"](PP)).program()
+    _, status, _ = det.preproc(mosaic, xy, 192, 192, 192, cfg)
+    assert status.cpu().tolist() == [0, 1, 2, 0]
+
+
+def test_big512_sample_fp32():
+    from oracle import preprocessing_ref as P
+    det = detector("fp32", max_imgsz=640)
+    g = np.load(os.path.join(ROOT, "tests/golden/preproc.npz"))
+    img = g["in/big512"]
+    mosaic, xy = _mosaic(det, [img])
+    for pname in ("zscale_minmax", "chan3_minmax", "full"):
+        cfg = PP.DataPreprocessor(PIPES[pname](PP)).program()
+        netin, status, lb = det.preproc(mosaic, xy, 512, 512, 512, cfg)
+        got = netin[0].float().cpu().numpy()[..., :3][..., ::-1].reshape(-1, 3)[::97]
+        ref = (g["big512_sample/%s" % pname].astype(np.float32) / np.float32(255)).astype(np.float32)
+        np.testing.assert_allclose(got, ref, rtol=0, atol=2e-7)
