@@ -31,7 +31,7 @@ def _oracle_forward(images, imgsz):
     return x, raw.permute(0, 2, 1).contiguous(), m.net.taps
 
 
-TAPS = ["model.0", "model.1", "model.2.cv1", "model.2.m.0.cv1", "model.2.m.0.cv2", "model.2.cv2", "model.4.cv2",
+TAPS = ["model.0", "model.1", "model.2.cv1", "model.2.m.2.cv1", "model.12.m.0.cv2", "model.2.cv2", "model.4.cv2",
         "model.6.cv2", "model.8.cv2", "model.9.cv1", "model.9.cv2", "model.12.cv1", "model.12.cv2", "model.15.cv1",
         "model.15.cv2", "model.16", "model.18.cv2", "model.19", "model.21.cv2", "model.22.cv2.0.1", "model.22.cv3.2.1"]
 
