@@ -377,8 +377,7 @@ __global__ __launch_bounds__(NT) void pre_stats_kernel(const PreArgs a) {
     const PreProgram& pg = a.prog[p];
     double* params = a.params + ((size_t)b * 3 + p) * PSTRIDE;
     double* heq = a.histeq + ((size_t)b * 3 + p) * HEQ_STRIDE;
-    const int* tl = a.tiles + 4 * b;
-    TileView tv{a.mosaic + (size_t)tl[1] * a.MW + tl[0], a.MW, a.tw, a.th, a.tw * a.th};
+    TileView tv{a.mosaic + (size_t)a.txy[2 * b + 1] * a.MW + a.txy[2 * b], a.MW, a.tw, a.th, a.tw * a.th};
     int status = 0;
     for (int k = 0; k < pg.n; ++k) {
         const PreStage& st = pg.st[k];
@@ -430,8 +429,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void pre_pack_kernel(const PreArgs a) {
     typedef T vec4 __attribute__((ext_vector_type(4)));
     const int b = blockIdx.y;
-    const int* tl = a.tiles + 4 * b;
-    const float* base = a.mosaic + (size_t)tl[1] * a.MW + tl[0];
+    const float* base = a.mosaic + (size_t)a.txy[2 * b + 1] * a.MW + a.txy[2 * b];
     const int npx = a.H * a.W;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < npx; i += gridDim.x * 256) {
         const int Y = i / a.W, X = i - Y * a.W;
@@ -451,8 +449,7 @@ __global__ __launch_bounds__(256) void pre_pack_kernel(const PreArgs a) {
 // resize path: first the preprocessed tile in float64 planes, then cv2-style bilinear (float32 coordinates/weights)
 __global__ __launch_bounds__(256) void pre_plane_kernel(const PreArgs a) {
     const int b = blockIdx.y;
-    const int* tl = a.tiles + 4 * b;
-    const float* base = a.mosaic + (size_t)tl[1] * a.MW + tl[0];
+    const float* base = a.mosaic + (size_t)a.txy[2 * b + 1] * a.MW + a.txy[2 * b];
     const int npx = a.th * a.tw;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < npx; i += gridDim.x * 256) {
         const int y = i / a.tw, x = i - y * a.tw;
@@ -501,8 +498,7 @@ __global__ __launch_bounds__(256) void pre_resize_pack_kernel(const PreArgs a) {
 __global__ __launch_bounds__(256) void pre_rowcheck_kernel(const PreArgs a) {
     __shared__ double smn[4], smx[4];
     const int b = blockIdx.x;
-    const int* tl = a.tiles + 4 * b;
-    const float* base = a.mosaic + (size_t)tl[1] * a.MW + tl[0];
+    const float* base = a.mosaic + (size_t)a.txy[2 * b + 1] * a.MW + a.txy[2 * b];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int bad = 0;
     for (int row = 0; row < 3 && row < a.th; ++row) {

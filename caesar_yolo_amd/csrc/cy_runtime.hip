@@ -35,6 +35,11 @@ struct cy_ctx {
     int* d_tiles = nullptr; double* pre_params = nullptr; double* pre_histeq = nullptr; double* pre_scratch = nullptr;
     size_t pre_scratch_elems = 0;
     int cap = 0, cap_pow2 = 0;
+    // optional per-launch timing of the forward ops (hipEvents on the caller's stream)
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
+    struct ProfRec { size_t e0, e1; int kind; double flops; };
+    std::vector<ProfRec> prof;
 };
 
 namespace {
@@ -58,6 +63,8 @@ size_t tensor_elems_per_tile(const Plan& p, int H, int W) {
 }
 
 void free_all(cy_ctx* c) {
+    for (auto e : c->ev_pool) hipEventDestroy(e);
+    c->ev_pool.clear(); c->ev_used = 0; c->prof.clear();
     for (auto& d : c->dconv) { if (d.w) hipFree(d.w); if (d.bias) hipFree(d.bias); if (d.stem_w) hipFree(d.stem_w); }
     c->dconv.clear();
     void* ptrs[] = {c->ws, c->netin, c->pred, c->cand, c->cand_anchor, c->cand_count, c->keys, c->mask, c->det,
@@ -276,6 +283,18 @@ int cy_forward(cy_ctx* c, const void* d_netin, int B, int H, int W, float* d_pre
     int a_off[3], acc = 0;
     for (int l = 0; l < 3; ++l) { a_off[l] = acc; acc += (H >> (3 + l)) * (W >> (3 + l)); }
     auto tptr = [&](int t) -> char* { return t == 0 ? (char*)const_cast<void*>(d_netin) : c->ws + c->toff[t]; };
+    auto stamp = [&]() -> size_t {
+        if (c->ev_used == c->ev_pool.size()) { hipEvent_t e; hipEventCreate(&e); c->ev_pool.push_back(e); }
+        hipEventRecord(c->ev_pool[c->ev_used], s);
+        return c->ev_used++;
+    };
+    size_t ev_prev = c->profiling ? stamp() : 0;
+    auto prof_done = [&](int kind, double flops) {
+        if (!c->profiling) return;
+        const size_t e = stamp();
+        c->prof.push_back({ev_prev, e, kind, flops});
+        ev_prev = e;
+    };
     for (const Op& o : p.ops) {
         if (o.kind == OPK_STEM) {
             const Tensor& ti = p.tensors[o.in0]; const Tensor& to = p.tensors[o.out];
@@ -284,12 +303,14 @@ int cy_forward(cy_ctx* c, const void* d_netin, int B, int H, int W, float* d_pre
             a.B = B; a.Hi = H >> ti.level; a.Wi = W >> ti.level; a.Ho = H >> to.level; a.Wo = W >> to.level;
             a.Cout = p.convs[o.conv].cout; a.out_ct = to.C; a.out_coff = o.out_coff;
             HIPCHK(c, launch_stem(c->prec, a, s));
+            prof_done(2, 2.0 * B * a.Ho * a.Wo * a.Cout * 27.0);
         } else if (o.kind == OPK_POOL) {
             const Tensor& t = p.tensors[o.in0];
             PoolArgs a{};
             a.src = tptr(o.in0); a.dst = tptr(o.out); a.ct = t.C; a.src_coff = o.in0_coff; a.dst_coff = o.out_coff;
             a.C = o.c0; a.B = B; a.H = H >> t.level; a.W = W >> t.level;
             HIPCHK(c, launch_pool5(c->prec, a, s));
+            prof_done(3, 0.0);
         } else {
             const ConvDesc& d = p.convs[o.conv];
             ConvArgs a{};
@@ -314,9 +335,31 @@ int cy_forward(cy_ctx* c, const void* d_netin, int B, int H, int W, float* d_pre
             }
             if (o.res >= 0) { a.res = tptr(o.res); a.res_ct = p.tensors[o.res].C; a.res_coff = o.res_coff; }
             HIPCHK(c, launch_conv(c->prec, a, s));
+            prof_done(pad64(a.Cout) <= 64 ? 1 : 0, 2.0 * B * a.Ho * a.Wo * (double)a.Cout * a.Cin * a.k * a.k);
         }
     }
     return CY_OK;
+}
+
+int cy_profile_enable(cy_ctx* c, int on) {
+    if (!c) return CY_ERR_ARG;
+    c->profiling = on != 0;
+    c->prof.clear(); c->ev_used = 0;
+    return CY_OK;
+}
+
+int cy_profile_summary(cy_ctx* c, cy_prof_entry* out, int cap) {
+    // kinds: 0 conv_igemm 128x128 tile, 1 conv_igemm 128x64 tile, 2 stem, 3 pool5
+    if (!c || !out || cap < 4) return fail(c, CY_ERR_ARG, "bad arguments");
+    HIPCHK(c, hipDeviceSynchronize());
+    const char* nm[4] = {"conv_igemm_kernel<2,2,4> (128x128)", "conv_igemm_kernel<4,1,2> (128x64)", "stem_kernel", "pool5_kernel"};
+    for (int k = 0; k < 4; ++k) { memset(&out[k], 0, sizeof(out[k])); strncpy(out[k].kernel, nm[k], sizeof(out[k].kernel) - 1); }
+    for (const auto& r : c->prof) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->ev_pool[r.e0], c->ev_pool[r.e1]) != hipSuccess) continue;
+        out[r.kind].ms += ms; out[r.kind].flops += r.flops; out[r.kind].launches += 1;
+    }
+    return 4;
 }
 
 int cy_debug_read_conv(cy_ctx* c, const char* conv_name, float* h_out, size_t cap, int* dims4) {
@@ -394,17 +437,15 @@ int cy_preproc(cy_ctx* c, const float* d_mosaic, int MH, int MW, const int* h_ti
     cy_letterbox lb;
     if (cy_letterbox_geometry(th, tw, imgsz, &lb)) return fail(c, CY_ERR_ARG, "bad tile/imgsz");
     if (lb.H > c->cfg.max_h || lb.W > c->cfg.max_w) return fail(c, CY_ERR_ARG, "letterboxed tile exceeds max_h/max_w of the context");
-    std::vector<int> t4(4 * B);
+    if (B > MAX_PRE_BATCH) return fail(c, CY_ERR_ARG, "at most 128 tiles per cy_preproc call");
+    PreArgs a{};
     for (int b = 0; b < B; ++b) {
-        t4[4 * b] = h_tiles[2 * b]; t4[4 * b + 1] = h_tiles[2 * b + 1]; t4[4 * b + 2] = tw; t4[4 * b + 3] = th;
+        a.txy[2 * b] = h_tiles[2 * b]; a.txy[2 * b + 1] = h_tiles[2 * b + 1];
         if (h_tiles[2 * b] < 0 || h_tiles[2 * b + 1] < 0 || h_tiles[2 * b] + tw > MW || h_tiles[2 * b + 1] + th > MH)
             return fail(c, CY_ERR_ARG, "tile outside the mosaic");
     }
     hipStream_t s = (hipStream_t)stream;
-    HIPCHK(c, hipMemcpyAsync(c->d_tiles, t4.data(), 4 * B * sizeof(int), hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipStreamSynchronize(s));     // t4 is a stack-lifetime staging buffer
-    PreArgs a{};
-    a.mosaic = d_mosaic; a.MH = MH; a.MW = MW; a.tiles = c->d_tiles; a.B = B; a.th = th; a.tw = tw;
+    a.mosaic = d_mosaic; a.MH = MH; a.MW = MW; a.B = B; a.th = th; a.tw = tw;
     a.nprog = cfg->nprog;
     for (int i = 0; i < 3; ++i) {
         a.prog[i].n = cfg->prog[i].n;

@@ -1,0 +1,270 @@
+"""Tile scheduler + catalog: host mirror of the reference's `SFinder` (caesar_yolo/inference.py:280-1288) for the
+MI355X path.
+
+Same public surface -- `SFinder(model, config).run()` (single frame, :485-552) and `.run_parallel()` (tiled, :578-658),
+int status returns, `catalog_<image_id>.json` / `out_<image_id>.json` outputs -- but a different engine:
+
+  * the mosaic is read once, lives in HBM, and tiles are cropped on device (reference: every tile re-opens the file,
+    caesar_yolo/inference.py:190-195);
+  * tiles are grouped by shape and run through the whole per-tile path in batches (`cy_detect_tiles`); the reference
+    runs batch 1 sequentially (:611-622);
+  * ranks are one process per GPU under torch.distributed; tile t of a shape class goes to rank (contiguous chunks),
+    and the only exchange is ONE all-gather of fixed-capacity detection records (replaces the pickled send/recv of
+    :936-984).  Tile geometry is recomputed identically on every rank, so only detections travel;
+  * the cross-tile merge (:663-726, :731-931) runs in the library's host code on tile-id-ordered records, which makes
+    the catalog independent of the number of GPUs (the reference's source numbering depends on the MPI rank count,
+    SURVEY.md section 8 a12; this build fixes the order to the 1-process order).
+"""
+import ctypes as C
+import json
+import logging
+import os
+import time
+import numpy as np
+import torch
+
+from . import lib as L
+from . import utils
+from .preprocessing import no_preprocessing
+
+logger = logging.getLogger("caesar_yolo_amd")
+
+
+def shard(items, rank, world):
+    """Contiguous chunk `rank` of `world` (sizes differ by at most one)."""
+    n = len(items)
+    lo = (n * rank) // world
+    hi = (n * (rank + 1)) // world
+    return items[lo:hi]
+
+
+class TileEngine(object):
+    """Runs the per-tile path for this rank's share of a tile grid and merges all ranks' detections."""
+
+    def __init__(self, detector, mosaic_dev, grid, pre_cfg, imgsz, conf, iou, soft, hard, rank=0, world=1, batch=64):
+        self.det, self.mosaic, self.grid = detector, mosaic_dev, [tuple(int(v) for v in t) for t in grid]
+        self.pre_cfg, self.imgsz = pre_cfg, int(imgsz)
+        self.conf, self.iou, self.soft, self.hard = float(conf), float(iou), float(soft), float(hard)
+        self.rank, self.world, self.batch = rank, world, min(int(batch), detector.max_batch)
+        # shape classes in order of first appearance; every rank derives the same assignment
+        classes = {}
+        for tid, (x0, x1, y0, y1) in enumerate(self.grid):
+            classes.setdefault((y1 - y0, x1 - x0), []).append(tid)
+        self.classes = classes
+        self.my = {shp: shard(tids, rank, world) for shp, tids in classes.items()}
+        self.cap_tiles = max(sum(len(shard(t, r, world)) for t in classes.values()) for r in range(world))
+        n_my = sum(len(v) for v in self.my.values())
+        dev = detector.tdev
+        # fixed-capacity record buffer: [tile][300*6 floats | count | status | tile id]
+        self.rec = torch.zeros((self.cap_tiles, L.CY_MAX_DET * 6 + 3), dtype=torch.float32, device=dev)
+        self.det_buf = torch.empty((self.batch, L.CY_MAX_DET, 6), dtype=torch.float32, device=dev)
+        self.cnt_buf = torch.empty((self.batch,), dtype=torch.int32, device=dev)
+        self.st_buf = torch.empty((self.batch,), dtype=torch.int32, device=dev)
+        self.n_my = n_my
+        self.gathered = None
+
+    def run_local(self):
+        """Enqueue every batch of this rank's tiles; results stay on device in self.rec."""
+        row = 0
+        self.rec.zero_()
+        for (th, tw), tids in self.my.items():
+            for i in range(0, len(tids), self.batch):
+                chunk = tids[i:i + self.batch]
+                B = len(chunk)
+                xy = [(self.grid[t][0], self.grid[t][2]) for t in chunk]
+                out = (self.det_buf[:B], self.cnt_buf[:B], self.st_buf[:B])
+                self.det.detect_tiles(self.mosaic, xy, th, tw, self.imgsz, self.pre_cfg, self.conf, self.iou,
+                                      self.soft, self.hard, out=out)
+                r = self.rec[row:row + B]
+                r[:, :L.CY_MAX_DET * 6] = self.det_buf[:B].reshape(B, -1)
+                r[:, -3] = self.cnt_buf[:B].float()
+                r[:, -2] = self.st_buf[:B].float()
+                r[:, -1] = torch.tensor(chunk, dtype=torch.float32, device=r.device)
+                row += B
+        return row
+
+    def gather(self):
+        """ONE collective: all-gather of the fixed-capacity record buffers (RCCL over xGMI when world > 1)."""
+        if self.world > 1:
+            import torch.distributed as dist
+            out = torch.empty((self.world,) + tuple(self.rec.shape), dtype=self.rec.dtype, device=self.rec.device)
+            dist.all_gather_into_tensor(out, self.rec)
+            self.gathered = out.reshape(-1, self.rec.shape[1])
+            self._valid = []
+            for r in range(self.world):
+                n = sum(len(shard(t, r, self.world)) for t in self.classes.values())
+                self._valid.append((r * self.cap_tiles, n))
+        else:
+            self.gathered = self.rec
+            self._valid = [(0, self.n_my)]
+        return self.gathered
+
+    def catalog(self, names):
+        """Records of all ranks -> tile-id order -> edge flags + cross-tile merge -> the reference's source dicts."""
+        g = self.gathered.cpu().numpy()
+        rows = np.concatenate([g[o:o + n] for o, n in self._valid], 0) if self._valid else g[:0]
+        return build_catalog(rows, self.grid, names)
+
+
+def build_catalog(rows, grid, names):
+    """rows: [ntiles, 300*6+3] host records (any order).  Returns (sources list, per-tile stats dict)."""
+    tid = rows[:, -1].astype(np.int64)
+    order = np.argsort(tid, kind="stable")
+    rows = rows[order]
+    cnt = rows[:, -3].astype(np.int64)
+    status = rows[:, -2].astype(np.int64)
+    dets, dtile = [], []
+    for r in range(rows.shape[0]):
+        if status[r] != 0 or cnt[r] == 0:
+            continue
+        dets.append(rows[r, :cnt[r] * 6].reshape(-1, 6))
+        dtile.append(np.full(cnt[r], rows[r, -1], np.int32))
+    stats = {"tiles": int(rows.shape[0]), "skipped": int(np.sum(status != 0)), "per_tile_detections": int(cnt[status == 0].sum())}
+    if not dets:
+        return [], stats
+    det = np.ascontiguousarray(np.concatenate(dets, 0), np.float32)
+    dtile = np.ascontiguousarray(np.concatenate(dtile, 0), np.int32)
+    tiles = np.ascontiguousarray(np.array(grid, np.int32).reshape(-1, 4))
+    n, T = det.shape[0], tiles.shape[0]
+    lib = L.load()
+    ip, fp, dp = C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_double)
+    rec = np.zeros((n, 8), np.float64)
+    L.check(lib.cy_make_tile_records(det.ctypes.data_as(fp), dtile.ctypes.data_as(ip), n, tiles.ctypes.data_as(ip), T,
+                                     rec.ctypes.data_as(dp)))
+    out = np.zeros((n, 8), np.float64)
+    m = L.check(lib.cy_merge_edge_sources(rec.ctypes.data_as(dp), n, tiles.ctypes.data_as(ip), T, out.ctypes.data_as(dp)))
+    return records_to_sources(out[:m], names), stats
+
+
+_EDGE = {0.0: 0, 1.0: 1, 2.0: True}        # the reference mixes int and bool in this field
+
+
+def records_to_sources(out, names):
+    src = []
+    for i in range(out.shape[0]):
+        x1, y1, x2, y2, score, cid, e, m = out[i]
+        src.append({"name": "S%d" % (i + 1), "x1": float(x1), "x2": float(x2), "y1": float(y1), "y2": float(y2),
+                    "class_id": int(cid), "class_name": str(names[int(cid)]), "score": float(score),
+                    "edge": _EDGE[float(e)], "merged": bool(m)})
+    return src
+
+
+def objs_from_detections(det, names, nx, ny, xmin=0, ymin=0, tag=""):
+    """Analyzer.make_json_results (caesar_yolo/evaluation.py:418-469) for one frame: int() truncation, edge rule."""
+    objs = []
+    for i in range(det.shape[0]):
+        x1, y1, x2, y2 = (int(v) for v in det[i, :4])
+        at_edge = (x1 <= 0 or x1 >= nx - 1 or x2 <= 0 or x2 >= nx - 1 or y1 <= 0 or y1 >= ny - 1 or y2 <= 0 or y2 >= ny - 1)
+        cid = int(det[i, 5])
+        objs.append({"name": "S%d" % (i + 1) + ("_" + tag if tag else ""), "x1": float(xmin + x1), "x2": float(xmin + x2),
+                     "y1": float(ymin + y1), "y2": float(ymin + y2), "class_id": cid, "class_name": str(names[cid]),
+                     "score": float(det[i, 4]), "edge": int(at_edge)})
+    return objs
+
+
+class SFinder(object):
+    """caesar_yolo/inference.py:280: `SFinder(model, config)`; `run()` / `run_parallel()` return 0 or -1."""
+
+    def __init__(self, model, config):
+        self.model, self.config = model, config
+        self.sources = {"sources": []}
+        self.results = {}
+        self.image_id = ""
+        self.nx = self.ny = -1
+        self.outfile_json = config.get('outfile_json', '')
+        self.write_to_json = config.get('save_catalog', True)
+        self.runtime = 0.0
+        self.stats = {}
+
+    # ---- shared
+    def _load_mosaic(self):
+        path = self.config['image_path']
+        if os.path.splitext(path)[1] != '.fits':
+            logger.error("Only FITS images are supported on the HIP path")
+            return None
+        res = utils.read_fits_image(path)
+        if res is None:
+            return None
+        data, self.header = res
+        self.image_id = utils.image_id_of(path)
+        self.ny, self.nx = data.shape
+        det = self.model.engine(self._device())
+        return det, det.mosaic_to_device(data, big_endian=True)
+
+    def _device(self):
+        devs = self.config.get('devices', ['0'])
+        rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.config.get('use_multi_gpu') and len(devs) > rank:
+            return devs[rank]                      # caesar_yolo/inference.py:207-210: device = devices[procId]
+        d = devs[0]
+        return int(os.environ.get("LOCAL_RANK", "0")) if d in ("cpu", "") else d
+
+    def _pre_cfg(self):
+        dp = self.config.get('preprocess_fcn')
+        return dp.program() if dp is not None else no_preprocessing()
+
+    def _thr(self):
+        c = self.config
+        return c['score_thr'], c['iou_thr'], c['merge_overlap_iou_thr_soft'], c['merge_overlap_iou_thr_hard']
+
+    # ---- serial: one frame (reference :485-552 + Analyzer.predict)
+    def run(self):
+        m = self._load_mosaic()
+        if m is None:
+            logger.error("Failed to read image %s!" % self.config['image_path'])
+            return -1
+        det, mosaic = m
+        conf, iou, soft, hard = self._thr()
+        try:
+            d, cnt, status = det.detect_tiles(mosaic, [(0, 0)], self.ny, self.nx, self.config['img_size'], self._pre_cfg(),
+                                              conf, iou, soft, hard)
+            torch.cuda.synchronize(det.tdev)
+        except L.CyError as e:
+            logger.warning("Model prediction failed (err=%s)..." % str(e))
+            return -1
+        if int(status[0]) != 0:
+            logger.warning("Input image rejected by preprocessing (status %d), no prediction made." % int(status[0]))
+            return -1
+        dd = d[0, :int(cnt[0])].cpu().numpy()
+        self.results = {"image_id": self.image_id, "objs": objs_from_detections(dd, self.model.names, self.nx, self.ny)}
+        if self.write_to_json:
+            out = self.outfile_json or ('out_' + str(self.image_id) + '.json')
+            with open(out, 'w') as fp:
+                json.dump(self.results, fp, indent=2, sort_keys=True)
+        return 0
+
+    # ---- tiled (reference :578-658)
+    def run_parallel(self):
+        import torch.distributed as dist
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        rank = dist.get_rank() if world > 1 else 0
+        t0 = time.time()
+        m = self._load_mosaic()
+        if m is None:
+            return -1
+        det, mosaic = m
+        c = self.config
+        tsx, tsy = (c['tile_xsize'], c['tile_ysize']) if c['split_image_in_tiles'] else (self.nx, self.ny)
+        stx, sty = (c['tile_xstep'], c['tile_ystep']) if c['split_image_in_tiles'] else (1, 1)
+        grid = utils.generate_tiles(0, self.nx - 1, 0, self.ny - 1, tsx, tsy, stx, sty)
+        if grid is None:
+            logger.warning("[PROC %d] Failure in create tile tasks, exit..." % rank)
+            return -1
+        conf, iou, soft, hard = self._thr()
+        eng = TileEngine(det, mosaic, grid, self._pre_cfg(), c['img_size'], conf, iou, soft, hard, rank, world,
+                         c.get('tile_batch', 64))
+        eng.run_local()
+        eng.gather()
+        if rank == 0:
+            src, self.stats = eng.catalog(self.model.names)
+            self.sources = {"sources": src}
+            if self.write_to_json:
+                out = self.outfile_json or ('catalog_' + str(self.image_id) + '.json')
+                with open(out, 'w') as fp:
+                    json.dump(self.sources, fp, indent=2, sort_keys=True)
+        if world > 1:
+            dist.barrier()
+        self.runtime = time.time() - t0
+        if rank == 0:
+            logger.info("[PROC %d] Run completed in %d seconds" % (rank, self.runtime))
+        return 0

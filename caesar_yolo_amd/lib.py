@@ -16,7 +16,7 @@ F16, F32 = 0, 1
 EXPORTS = [
     "cy_create", "cy_destroy", "cy_last_error", "cy_load_weights", "cy_load_weights_mem", "cy_num_classes",
     "cy_class_name", "cy_plan_num_convs", "cy_plan_conv_desc", "cy_letterbox_geometry", "cy_num_anchors",
-    "cy_pred_elems", "cy_mosaic_prepare", "cy_letterbox_pack", "cy_preproc", "cy_preproc_params", "cy_forward", "cy_debug_read_conv",
+    "cy_pred_elems", "cy_profile_enable", "cy_profile_summary", "cy_mosaic_prepare", "cy_letterbox_pack", "cy_preproc", "cy_preproc_params", "cy_forward", "cy_debug_read_conv",
     "cy_decode_nms", "cy_iou_merge", "cy_detect_tiles", "cy_conv_bn_silu", "cy_make_tile_records",
     "cy_merge_edge_sources",
 ]
@@ -46,6 +46,10 @@ class cy_preproc_cfg(C.Structure):
 class cy_conv_desc(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("cin", C.c_int), ("cout", C.c_int), ("k", C.c_int), ("s", C.c_int),
                 ("act", C.c_int)]
+
+
+class cy_prof_entry(C.Structure):
+    _fields_ = [("kernel", C.c_char * 48), ("ms", C.c_double), ("flops", C.c_double), ("launches", C.c_long)]
 
 
 class cy_letterbox(C.Structure):
@@ -85,6 +89,8 @@ def load():
         "cy_preproc_params": (C.c_int, [vp, dp, C.c_int]),
         "cy_letterbox_pack": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
         "cy_forward": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+        "cy_profile_enable": (C.c_int, [vp, C.c_int]),
+        "cy_profile_summary": (C.c_int, [vp, C.POINTER(cy_prof_entry), C.c_int]),
         "cy_debug_read_conv": (C.c_int, [vp, C.c_char_p, fp, C.c_size_t, ip]),
         "cy_decode_nms": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                     vp, vp, vp, vp]),

@@ -121,6 +121,14 @@ class HipDetector(object):
         self._chk(self.lib.cy_forward(self.ctx, self._p(netin), B, H, Wd, self._p(pred), self._stream()))
         return pred
 
+    def profile(self, on):
+        self._chk(self.lib.cy_profile_enable(self.ctx, int(bool(on))))
+
+    def profile_summary(self):
+        ent = (L.cy_prof_entry * 4)()
+        n = self._chk(self.lib.cy_profile_summary(self.ctx, ent, 4))
+        return [dict(kernel=ent[i].kernel.decode(), ms=ent[i].ms, flops=ent[i].flops, launches=ent[i].launches) for i in range(n)]
+
     def read_conv(self, name, shape_hint_elems):
         buf = np.zeros(shape_hint_elems, np.float32)
         dims = (C.c_int * 4)()
@@ -209,7 +217,8 @@ class YOLO(object):
             parts = weights.split(":")
             scale, nc = parts[1], int(parts[2])
             seed = int(parts[3]) if len(parts) > 3 else 20260104
-            cache = os.environ.get("CAESAR_YOLO_CACHE", os.path.join(os.path.expanduser("~"), ".cache", "caesar_yolo_amd"))
+            import tempfile
+            cache = os.environ.get("CAESAR_YOLO_CACHE", os.path.join(tempfile.gettempdir(), "caesar_yolo_amd_%d" % os.getuid()))
             os.makedirs(cache, exist_ok=True)
             path = os.path.join(cache, "seeded_%s_nc%d_%d.cyw" % (scale, nc, seed))
             if not os.path.exists(path):

@@ -95,6 +95,12 @@ int cy_letterbox_pack(cy_ctx* ctx, const double* d_planes, int B, int h0, int w0
 
 /* DetectionModel.forward: d_netin [B][H][W][4] -> d_pred [B][A][64+nc] fp32 raw head output */
 int cy_forward(cy_ctx* ctx, const void* d_netin, int B, int H, int W, float* d_pred, void* stream);
+/* per-launch timing of the forward kernels with hipEvents on the caller's stream (bench.py roofline): enable, run
+ * cy_forward / cy_detect_tiles as usual, then read the totals per kernel (entries: both conv_igemm tile variants,
+ * stem, pool); flops are the ALGORITHMIC 2*MACs of the launches timed */
+typedef struct cy_prof_entry { char kernel[48]; double ms; double flops; long launches; } cy_prof_entry;
+int cy_profile_enable(cy_ctx* ctx, int on);
+int cy_profile_summary(cy_ctx* ctx, cy_prof_entry* out, int cap);
 /* copy the output of one named convolution of the last cy_forward to host as fp32 [B][C][Ho][Wo] (test hook) */
 int cy_debug_read_conv(cy_ctx* ctx, const char* conv_name, float* h_out, size_t cap_elems, int* dims4);
 
