@@ -88,7 +88,12 @@ class TileEngine(object):
         if self.world > 1:
             import torch.distributed as dist
             out = torch.empty((self.world,) + tuple(self.rec.shape), dtype=self.rec.dtype, device=self.rec.device)
-            dist.all_gather_into_tensor(out, self.rec)
+            if dist.get_backend() == "gloo":          # CPU rehearsal of the same collective (tests)
+                parts = [torch.empty_like(self.rec) for _ in range(self.world)]
+                dist.all_gather(parts, self.rec)
+                out = torch.stack(parts, 0)
+            else:
+                dist.all_gather_into_tensor(out, self.rec)
             self.gathered = out.reshape(-1, self.rec.shape[1])
             self._valid = []
             for r in range(self.world):
