@@ -11,12 +11,13 @@
 //   contiguous channels of a pixel and the NHWC store is 16-byte vectors (no LDS transpose in the epilogue).
 //   f16: v_mfma_f32_16x16x32_f16 (fp32 accumulate).  f32 (parity mode): v_mfma_f32_16x16x4_f32 = exact fp32 FMA chain.
 //
-// Data movement: K is walked in 128-byte slabs per row (64 halves / 32 floats of one filter tap).  Each thread
-// fetches 16-byte pieces with buffer loads whose hardware range check supplies the zero padding of the 3x3 halo
-// and of ragged channel counts (an out-of-range offset reads 0), stages them in registers while the previous slab
-// is on the matrix pipe, and writes them to a double-buffered, XOR-swizzled LDS image that ds_read_b128 reads
-// conflict-free (slot = chunk ^ ((row>>1)&7); a 256-byte bank row holds two 128-byte tile rows).
+// Data movement: K is walked in 128-byte slabs per row (64 halves / 32 floats of one filter tap).  Each lane moves
+// 16-byte pieces global -> LDS directly (`buffer_load_dwordx4 ... lds`, no VGPR staging, no ds_write); the buffer
+// range check supplies the zero padding of the 3x3 halo and of ragged channel counts (an out-of-range offset
+// writes 0).  The LDS image is double-buffered and XOR-swizzled through the SOURCE address so that ds_read_b128
+// fragment reads are conflict-free (slot = chunk ^ ((row>>1)&7); a 256-byte bank row holds two 128-byte tile rows).
 #include "cy_kernels.h"
+#include <cstdlib>
 
 namespace cy {
 
@@ -93,13 +94,21 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
         pix0[i] = p0; pix1[i] = p1; vmask[i] = vm;
     }
 
-    u32x4 ra[AROWS], rb[BROWS];
-    auto fetch = [&](int tap, int cc) {
-        const int c = cc * BKE + q * EPC;
+    // LDS-DMA staging: `buffer_load_dwordx4 ... lds` writes wave-uniform base + lane*16, i.e. one wave-instruction
+    // fills 8 consecutive 128-byte tile rows.  Row r = 8*wave + 32*i + (lane>>3), slot = lane&7 is exactly lane-linear,
+    // so the XOR swizzle moves to the SOURCE: the lane that owns slot s of row r fetches logical chunk s ^ ((r>>1)&7)
+    // (the same involution the fragment reads apply).  ((r>>1)&7 does not depend on i because 32*i>>1 is 0 mod 8.)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int cq = q ^ ((r0 >> 1) & 7);
+    typedef __attribute__((address_space(3))) void lds_void;
+    auto dma = [&](int stage, int tap, int cc) {
+        const int c = cc * BKE + cq * EPC;
         const int kh = tap / a.k, kw = tap - kh * a.k;
         const int dpix = kh * a.Wi + kw;
         const bool cin_ok = c < a.Cin;
-        const bool seg1 = c >= a.c0;
+        const bool seg1 = cc * BKE >= a.c0;               // wave-uniform: segment boundaries are multiples of BKE
+        char* A = smem + stage * STAGE + wave_u * (8 * 128);
+        char* Bm = A + A_BYTES;
 #pragma unroll
         for (int i = 0; i < AROWS; ++i) {
             const bool ok = cin_ok && ((vmask[i] >> tap) & 1u);
@@ -107,29 +116,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
             if (!seg1) off = (unsigned)((pix0[i] + (a.up0 ? 0 : dpix)) * a.in0_ct + a.in0_coff + c) * ES;
             else       off = (unsigned)((pix1[i] + dpix) * a.in1_ct + a.in1_coff + (c - a.c0)) * ES;
             off = ok ? off : CY_OOB;
-            ra[i] = seg1 ? __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 0, 0)
-                         : __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0);
+            lds_void* dst = (lds_void*)(A + i * (32 * 128));
+            if (seg1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, dst, 16, off, 0, 0, 0);
+            else      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, off, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < BROWS; ++i) {
             const int n = n0 + r0 + 32 * i;
             unsigned off = (unsigned)((n * taps + tap) * a.Cin + c) * ES;
             off = cin_ok ? off : CY_OOB;
-            rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsw, off, 0, 0);
-        }
-    };
-    auto stash = [&](int stage) {
-        char* A = smem + stage * STAGE;
-        char* Bm = A + A_BYTES;
-#pragma unroll
-        for (int i = 0; i < AROWS; ++i) {
-            const int r = r0 + 32 * i;
-            *reinterpret_cast<u32x4*>(A + r * 128 + ((q ^ ((r >> 1) & 7)) << 4)) = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < BROWS; ++i) {
-            const int r = r0 + 32 * i;
-            *reinterpret_cast<u32x4*>(Bm + r * 128 + ((q ^ ((r >> 1) & 7)) << 4)) = rb[i];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)(Bm + i * (32 * 128)), 16, off, 0, 0, 0);
         }
     };
 
@@ -187,18 +183,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
         }
     };
 
-    // ---- main loop: one barrier per slab; global loads for slab s+1 are in flight while slab s is on the MFMA pipe
+    // ---- main loop: the DMA for slab s+1 is in flight while slab s is on the matrix pipe; one barrier per slab
+    // (__syncthreads drains vmcnt, which is what orders the landed DMA before the next slab's ds_reads)
     int tap = 0, cc = 0;
-    fetch(0, 0);
-    stash(0);
+    dma(0, 0, 0);
     __syncthreads();
     for (int s = 0; s < nslab; ++s) {
         int ntap = tap, ncc = cc + 1;
         if (ncc == cchunks) { ncc = 0; ++ntap; }
-        const bool more = (s + 1) < nslab;
-        if (more) fetch(ntap, ncc);
+        if ((s + 1) < nslab) dma((s + 1) & 1, ntap, ncc);
         compute(s & 1);
-        if (more) stash((s + 1) & 1);
         __syncthreads();
         tap = ntap; cc = ncc;
     }
@@ -267,6 +261,200 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ 3x3 stride-1, halo reuse
+// 90 % of the network's FLOPs are 3x3 stride-1 convolutions.  As a plain implicit GEMM every filter tap re-fetches its
+// im2col rows, so a 128x128 tile moves 32 KB L2->LDS per 2.1 MFLOP (64 flop/B) and the kernel is bound by the L2->LDS
+// path, not by the matrix cores.  Here a workgroup owns a TH x 16 patch of output pixels of one image: per 64-channel
+// slab it stages the (TH+2) x 18 input halo ONCE and the nine taps read it at shifted rows (the MFMA B-operand row of a
+// lane is a pixel, so a tap is just a row offset in the LDS image), while only the 128 x 64 weight slab changes per tap.
+// L2->LDS traffic per flop drops ~3x (TH=16: 185 KB per 37.7 MFLOP = 204 flop/B).  Zero padding of the halo and of
+// ragged image edges comes from the buffer range check, as in the generic kernel.
+#define CY_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+
+template <int WM, int RING>
+__global__ __launch_bounds__(WM * 128) void conv3x3_halo_kernel(const ConvArgs a) {
+    constexpr int TH = 4 * WM, TW = 16, NT = WM * 128, NW = NT / 64, BN = 128;
+    constexpr int PR = (TH + 2) * (TW + 2);                 // halo rows (one row = one pixel, 64 channels = 128 B)
+    constexpr int NWI = (PR + 7) / 8;                        // wave-instructions per halo load (8 rows each)
+    constexpr int PROUNDS = (NWI + NW - 1) / NW;             // every wave issues exactly PROUNDS pieces (uniform vmcnt)
+    constexpr int P_BYTES = PROUNDS * NW * 1024, W_BYTES = BN * 128;
+    constexpr int WROUNDS = (BN / 8) / NW;
+    constexpr int DIST = RING - 1;                           // weight slabs in flight: tap t+DIST is fetched while tap t computes
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const Pbuf = smem;
+    char* const Wbuf = smem + 2 * P_BYTES;               // [halo 0 | halo 1 | weight ring]
+    typedef __attribute__((address_space(3))) void lds_void;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int H = a.Hi, W = a.Wi;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int ntn = (pad64(a.Cout) + BN - 1) / BN;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = id % ntn;
+    int rest = id / ntn;
+    const int tx = rest % tiles_x; rest /= tiles_x;
+    const int ty = rest % tiles_y;
+    const int b = rest / tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW, n0 = nt * BN;
+    const int chunks = a.Cin / 64;
+
+    const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in0), 0, a.in0_bytes, 0x00020000);
+    const auto rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wgt), 0, a.wgt_bytes, 0x00020000);
+
+    // ---- per-thread halo geometry: round j moves halo row (j*NW + wave)*8 + (lane>>3), LDS slot lane&7
+    unsigned poff[PROUNDS];
+#pragma unroll
+    for (int j = 0; j < PROUNDS; ++j) {
+        const int wi = j * NW + wave;
+        const int r = wi * 8 + (lane >> 3);
+        const int ry = r / (TW + 2), rx = r - ry * (TW + 2);
+        const int y = y0 + ry - 1, x = x0 + rx - 1;
+        const int q = (lane & 7) ^ ((r >> 1) & 7);
+        const bool ok = r < PR && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+        poff[j] = ok ? (unsigned)(((b * H + y) * W + x) * a.in0_ct + a.in0_coff + q * 8) * 2u : CY_OOB;
+    }
+    unsigned woff[WROUNDS];
+#pragma unroll
+    for (int j = 0; j < WROUNDS; ++j) {
+        const int row = (j * NW + wave) * 8 + (lane >> 3);
+        const int q = (lane & 7) ^ ((row >> 1) & 7);
+        woff[j] = (unsigned)((n0 + row) * 9 * a.Cin + q * 8) * 2u;
+    }
+    auto dma_patch = [&](int buf, int ch) {
+#pragma unroll
+        for (int j = 0; j < PROUNDS; ++j) {
+            const int wi = j * NW + wave;                   // rows >= PR land in the padded tail of the buffer as zeros
+            const unsigned off = poff[j] == CY_OOB ? CY_OOB : poff[j] + (unsigned)(ch * 128);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_void*)(Pbuf + buf * P_BYTES + wi * 1024), 16, off, 0, 0, 0);
+        }
+    };
+    auto dma_w = [&](int buf, int ch, int tap) {
+#pragma unroll
+        for (int j = 0; j < WROUNDS; ++j) {
+            const unsigned off = woff[j] + (unsigned)((tap * a.Cin + ch * 64) * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)(Wbuf + buf * W_BYTES + (j * NW + wave) * 1024), 16, off, 0, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+
+    auto compute = [&](const char* P, const char* Wb, int kh, int kw) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int qf = fq + 4 * kk;
+            f16x8 xa[4], wb[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int r = (wm * 4 + mi + kh) * (TW + 2) + kw + fr;
+                xa[mi] = *reinterpret_cast<const f16x8*>(P + r * 128 + ((qf ^ ((r >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int r = wn * 64 + ni * 16 + fr;
+                wb[ni] = *reinterpret_cast<const f16x8*>(Wb + r * 128 + ((qf ^ ((r >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0);
+        }
+    };
+
+    // ---- pipeline.  Weight slabs live in a 3-slot ring: the slab of tap t+2 is requested while tap t computes, so the
+    // wait in front of a barrier only covers a DMA issued a whole tap earlier (counted vmcnt, raw s_barrier: the most
+    // recent requests stay in flight across the barrier).  The next 64-channel halo is requested at tap 0 of a slab.
+    const int total = chunks * 9;
+    auto w_issue = [&](int n) { const int ch = n / 9; dma_w(n % RING, ch, n - ch * 9); };
+    dma_patch(0, 0);
+    w_issue(0);
+    if (DIST > 1 && total > 1) { w_issue(1); CY_WAIT_VM((DIST - 1) * WROUNDS); } else { CY_WAIT_VM(0); }
+    __builtin_amdgcn_s_barrier();
+    int it = 0;
+    for (int ch = 0; ch < chunks; ++ch) {
+        const char* P = Pbuf + (ch & 1) * P_BYTES;
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap, ++it) {
+            const bool pre_p = tap == 0 && ch + 1 < chunks, pre_w = it + DIST < total;
+            if (pre_p) dma_patch((ch + 1) & 1, ch + 1);
+            if (pre_w) w_issue(it + DIST);
+            const int kh = tap / 3, kw = tap - kh * 3;
+            compute(P, Wbuf + (it % RING) * W_BYTES, kh, kw);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this tap's fragment reads are done (WAR on the ring)
+            if (pre_w && DIST > 1) { CY_WAIT_VM((DIST - 1) * WROUNDS); }   // all but the newest slab request have landed
+            else { CY_WAIT_VM(0); }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+
+    // ---- epilogue (same per-lane channel layout as the generic kernel)
+    const int cbase = n0 + wn * 64 + fq * 16;
+    float bv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) bv[j] = a.bias[cbase + j];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int y = y0 + wm * 4 + mi, x = x0 + fr;
+        if (y >= H || x >= W) continue;
+        const long pix = ((long)b * H + y) * W + x;
+        float v[16];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float t = acc[ni][mi][j] + bv[ni * 4 + j];
+                if (a.act) t = silu_fast(t);
+                v[ni * 4 + j] = t;
+            }
+        if (cbase + 16 <= a.Cout) {
+            f16* dst = reinterpret_cast<f16*>(a.out) + pix * a.out_ct + a.out_coff + cbase;
+            if (a.res) {
+                const f16* rp = reinterpret_cast<const f16*>(a.res) + pix * a.res_ct + a.res_coff + cbase;
+                const f16x8 r0v = *reinterpret_cast<const f16x8*>(rp), r1v = *reinterpret_cast<const f16x8*>(rp + 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { v[j] += (float)r0v[j]; v[8 + j] += (float)r1v[j]; }
+            }
+            f16x8 o0, o1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { o0[j] = (f16)v[j]; o1[j] = (f16)v[8 + j]; }
+            *reinterpret_cast<f16x8*>(dst) = o0;
+            *reinterpret_cast<f16x8*>(dst + 8) = o1;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int c = cbase + j;
+                if (c >= a.Cout) continue;
+                float t = v[j];
+                if (a.res) t += (float)(reinterpret_cast<const f16*>(a.res)[pix * a.res_ct + a.res_coff + c]);
+                reinterpret_cast<f16*>(a.out)[pix * a.out_ct + a.out_coff + c] = (f16)t;
+            }
+        }
+    }
+}
+
+template <int WM, int RING>
+static hipError_t launch_halo(const ConvArgs& a, hipStream_t s) {
+    constexpr int TH = 4 * WM, NT = WM * 128;
+    constexpr int PR = (TH + 2) * 18, NWI = (PR + 7) / 8, NW = NT / 64, PROUNDS = (NWI + NW - 1) / NW;
+    const size_t lds = 2 * PROUNDS * NW * 1024 + RING * 128 * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<WM, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int blocks = a.B * ((a.Hi + TH - 1) / TH) * ((a.Wi + 15) / 16) * ((pad64(a.Cout) + 127) / 128);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<WM, RING>), dim3(blocks), dim3(NT), lds, s, a);
+    return hipGetLastError();
+}
+
 template <typename T, int WM, int WN, int MI>
 static hipError_t launch_t(const ConvArgs& a, hipStream_t s) {
     constexpr int BM = WM * MI * 16, BN = WN * 64;
@@ -285,6 +473,17 @@ static hipError_t launch_t(const ConvArgs& a, hipStream_t s) {
 
 hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s) {
     const bool narrow = pad64(a.Cout) <= 64;
+    // 3x3 stride-1 layers with >= 128 output channels: halo-reuse kernel (fp16 context only; the fp32 parity context keeps
+    // the generic kernel).  Small maps (fewer than ~2 blocks per CU at 16-row patches) use 8-row patches.
+    if (p == PREC_F16 && a.k == 3 && a.s == 1 && a.c1 == 0 && !a.up0 && !a.out_f32 && a.Cin % 64 == 0 && !narrow &&
+        a.out_bs == a.Ho * a.Wo && a.out_ro == 0) {
+        const long blocks16 = (long)a.B * ((a.Hi + 15) / 16) * ((a.Wi + 15) / 16) * ((pad64(a.Cout) + 127) / 128);
+        static const int force = getenv("CY_HALO_WM") ? atoi(getenv("CY_HALO_WM")) : 0;     // tuning override
+        if (force == 2) return launch_halo<2, 2>(a, s);
+        if (force == 4) return launch_halo<4, 2>(a, s);
+        if (force == 43) return launch_halo<4, 3>(a, s);
+        return launch_halo<2, 2>(a, s);
+    }
     if (p == PREC_F16) return narrow ? launch_t<f16, 4, 1, 2>(a, s) : launch_t<f16, 2, 2, 4>(a, s);
     return narrow ? launch_t<float, 4, 1, 2>(a, s) : launch_t<float, 2, 2, 4>(a, s);
 }

@@ -38,7 +38,7 @@ struct cy_ctx {
     // optional per-launch timing of the forward ops (hipEvents on the caller's stream)
     bool profiling = false;
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
-    struct ProfRec { size_t e0, e1; int kind; double flops; };
+    struct ProfRec { size_t e0, e1; int kind; double flops; int conv; };
     std::vector<ProfRec> prof;
 };
 
@@ -289,13 +289,15 @@ int cy_forward(cy_ctx* c, const void* d_netin, int B, int H, int W, float* d_pre
         return c->ev_used++;
     };
     size_t ev_prev = c->profiling ? stamp() : 0;
+    int cur_conv = -1;
     auto prof_done = [&](int kind, double flops) {
         if (!c->profiling) return;
         const size_t e = stamp();
-        c->prof.push_back({ev_prev, e, kind, flops});
+        c->prof.push_back({ev_prev, e, kind, flops, cur_conv});
         ev_prev = e;
     };
     for (const Op& o : p.ops) {
+        cur_conv = o.conv;
         if (o.kind == OPK_STEM) {
             const Tensor& ti = p.tensors[o.in0]; const Tensor& to = p.tensors[o.out];
             StemArgs a{};
@@ -360,6 +362,21 @@ int cy_profile_summary(cy_ctx* c, cy_prof_entry* out, int cap) {
         out[r.kind].ms += ms; out[r.kind].flops += r.flops; out[r.kind].launches += 1;
     }
     return 4;
+}
+
+int cy_profile_layers(cy_ctx* c, cy_prof_entry* out, int cap) {
+    if (!c || !c->loaded || !out) return fail(c, CY_ERR_ARG, "bad arguments");
+    const int n = (int)c->plan.convs.size();
+    if (cap < n) return fail(c, CY_ERR_ARG, "need one entry per conv");
+    HIPCHK(c, hipDeviceSynchronize());
+    for (int i = 0; i < n; ++i) { memset(&out[i], 0, sizeof(out[i])); strncpy(out[i].kernel, c->plan.convs[i].name.c_str(), sizeof(out[i].kernel) - 1); }
+    for (const auto& r : c->prof) {
+        if (r.conv < 0) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->ev_pool[r.e0], c->ev_pool[r.e1]) != hipSuccess) continue;
+        out[r.conv].ms += ms; out[r.conv].flops += r.flops; out[r.conv].launches += 1;
+    }
+    return n;
 }
 
 int cy_debug_read_conv(cy_ctx* c, const char* conv_name, float* h_out, size_t cap, int* dims4) {

@@ -129,6 +129,11 @@ class HipDetector(object):
         n = self._chk(self.lib.cy_profile_summary(self.ctx, ent, 4))
         return [dict(kernel=ent[i].kernel.decode(), ms=ent[i].ms, flops=ent[i].flops, launches=ent[i].launches) for i in range(n)]
 
+    def profile_layers(self):
+        ent = (L.cy_prof_entry * 256)()
+        n = self._chk(self.lib.cy_profile_layers(self.ctx, ent, 256))
+        return [dict(name=ent[i].kernel.decode(), ms=ent[i].ms, flops=ent[i].flops, launches=ent[i].launches) for i in range(n)]
+
     def read_conv(self, name, shape_hint_elems):
         buf = np.zeros(shape_hint_elems, np.float32)
         dims = (C.c_int * 4)()

@@ -101,6 +101,7 @@ int cy_forward(cy_ctx* ctx, const void* d_netin, int B, int H, int W, float* d_p
 typedef struct cy_prof_entry { char kernel[48]; double ms; double flops; long launches; } cy_prof_entry;
 int cy_profile_enable(cy_ctx* ctx, int on);
 int cy_profile_summary(cy_ctx* ctx, cy_prof_entry* out, int cap);
+int cy_profile_layers(cy_ctx* ctx, cy_prof_entry* out, int cap);    /* the same, one entry per convolution (graph order) */
 /* copy the output of one named convolution of the last cy_forward to host as fp32 [B][C][Ho][Wo] (test hook) */
 int cy_debug_read_conv(cy_ctx* ctx, const char* conv_name, float* h_out, size_t cap_elems, int* dims4);
 

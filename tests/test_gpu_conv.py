@@ -21,6 +21,9 @@ CASES = [  # B, H, W, Cin, Cout, k, s, act, residual
     (1, 64, 64, 64, 64, 3, 1, True, True),
     (4, 16, 16, 512, 256, 3, 1, True, False),
     (1, 5, 7, 8, 16, 3, 2, True, False),
+    (32, 64, 64, 64, 128, 3, 1, True, False),     # halo-reuse kernel, 16-row patches
+    (2, 50, 70, 128, 256, 3, 1, True, True),      # halo-reuse kernel, ragged patches + residual
+    (3, 33, 17, 192, 192, 3, 1, False, False),    # halo-reuse kernel, Cout not a multiple of 128, no activation
 ]
 
 
