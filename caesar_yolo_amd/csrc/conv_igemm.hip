@@ -31,7 +31,11 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define CY_OOB 0xFFFFFF00u
 
 __device__ __forceinline__ float silu_exact(float x) { return x / (1.0f + expf(-x)); }
-__device__ __forceinline__ float silu_fast(float x) { return x * __frcp_rn(1.0f + __expf(-x)); }
+// fp16 context: x * sigmoid(x) with the hardware exp2/rcp (1 ulp each; the result is rounded to fp16 anyway):
+// 5 VALU instructions per element instead of the ~50 of an IEEE-exact division
+__device__ __forceinline__ float silu_fast(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896341f));
+}
 
 template <typename T> struct Elem;
 template <> struct Elem<f16> { static constexpr int BKE = 64, EPC = 8, ES = 2; };
@@ -380,7 +384,7 @@ __global__ __launch_bounds__(WM * 128) void conv3x3_halo_kernel(const ConvArgs a
     int it = 0;
     for (int ch = 0; ch < chunks; ++ch) {
         const char* P = Pbuf + (ch & 1) * P_BYTES;
-#pragma unroll 1
+#pragma unroll
         for (int tap = 0; tap < 9; ++tap, ++it) {
             const bool pre_p = tap == 0 && ch + 1 < chunks, pre_w = it + DIST < total;
             if (pre_p) dma_patch((ch + 1) & 1, ch + 1);
@@ -440,6 +444,219 @@ __global__ __launch_bounds__(WM * 128) void conv3x3_halo_kernel(const ConvArgs a
     }
 }
 
+// ------------------------------------------------------------------------------------------------ 3x3 stride-1, ping-pong
+// Same data flow as conv3x3_halo_kernel (halo staged once per 64-channel slab, weights per tap), but the eight waves of
+// the workgroup run as two groups half an iteration apart (waves 0-3 / 4-7 = the two waves of each SIMD): while one
+// group issues its DMA pieces and fragment reads for tap t, its SIMD partner is on the matrix pipe with tap t (or t-1).
+// PMC on the lock-step version showed every SIMD's MFMA pipe only ~45 % busy with both waves waiting at the same
+// barrier; staggering by wave >= 4 is what MI355X_MICROARCH.md ("Two waves per SIMD", item 9) measures as the fix.
+//   group A (waves 0-3): LOAD(t) at half-step 2t,   COMPUTE(t) at 2t+1
+//   group B (waves 4-7): LOAD(t) at half-step 2t+1, COMPUTE(t) at 2t+2      (one s_barrier ends every half-step)
+// Weight slabs sit in a 4-slot ring and are requested two taps ahead: slot (t+2)%4 last held tap t-2, whose last reader
+// (B, half-step 2t-2) is done before A issues at 2t.  The halo of slab ch+1 is requested at tap 1 of slab ch.
+// Each wave waits (counted vmcnt) for everything but its newest requests at the end of LOAD; the following barrier
+// publishes the landed pieces to all readers.
+template <int NI>
+__global__ __launch_bounds__(512) void conv3x3_pp_kernel(const ConvArgs a) {
+    constexpr int TH = 16, TW = 16, NW = 8, WN = 2, BN = WN * NI * 16, RING = 4;
+    constexpr int PR = (TH + 2) * (TW + 2), NWI = (PR + 7) / 8, PROUNDS = (NWI + NW - 1) / NW;
+    constexpr int P_BYTES = (NWI + 1) * 1024, W_BYTES = BN * 128;       // +1 KB dummy row block for the padded rounds
+    constexpr int WPIECES = BN / 8, WROUNDS = (WPIECES + NW - 1) / NW;  // BN=128: 2 per wave; BN=64: 1 per wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const Pbuf = smem;
+    char* const Wbuf = smem + 2 * P_BYTES;
+    typedef __attribute__((address_space(3))) void lds_void;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int H = a.Hi, W = a.Wi;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int ntn = (pad64(a.Cout) + BN - 1) / BN;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = id % ntn;
+    int rest = id / ntn;
+    const int tx = rest % tiles_x; rest /= tiles_x;
+    const int ty = rest % tiles_y;
+    const int b = rest / tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW, n0 = nt * BN;
+    const int chunks = a.Cin / 64, total = chunks * 9;
+
+    const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in0), 0, a.in0_bytes, 0x00020000);
+    const auto rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wgt), 0, a.wgt_bytes, 0x00020000);
+
+    unsigned poff[PROUNDS];
+#pragma unroll
+    for (int j = 0; j < PROUNDS; ++j) {
+        const int r = (j * NW + wave) * 8 + (lane >> 3);
+        const int ry = r / (TW + 2), rx = r - ry * (TW + 2);
+        const int y = y0 + ry - 1, x = x0 + rx - 1;
+        const int q = (lane & 7) ^ ((r >> 1) & 7);
+        const bool ok = r < PR && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+        poff[j] = ok ? (unsigned)(((b * H + y) * W + x) * a.in0_ct + a.in0_coff + q * 8) * 2u : CY_OOB;
+    }
+    unsigned woff[WROUNDS];
+#pragma unroll
+    for (int j = 0; j < WROUNDS; ++j) {
+        const int row = ((j * NW + wave) % WPIECES) * 8 + (lane >> 3);
+        const int q = (lane & 7) ^ ((row >> 1) & 7);
+        woff[j] = (unsigned)((n0 + row) * 9 * a.Cin + q * 8) * 2u;
+    }
+    auto dma_patch = [&](int buf, int ch) {
+#pragma unroll
+        for (int j = 0; j < PROUNDS; ++j) {
+            const int wi = j * NW + wave;
+            const unsigned off = poff[j] == CY_OOB ? CY_OOB : poff[j] + (unsigned)(ch * 128);
+            char* dst = Pbuf + buf * P_BYTES + (wi < NWI ? wi : NWI) * 1024;      // rounds past the halo hit the dummy block
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_void*)dst, 16, off, 0, 0, 0);
+        }
+    };
+    auto dma_w = [&](int n) {                               // weight slab of global tap index n -> ring slot n % RING
+        const int ch = n / 9, tap = n - ch * 9;
+#pragma unroll
+        for (int j = 0; j < WROUNDS; ++j) {
+            const unsigned off = woff[j] + (unsigned)((tap * a.Cin + ch * 64) * 2);
+            char* dst = Wbuf + (n % RING) * W_BYTES + ((j * NW + wave) % WPIECES) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)dst, 16, off, 0, 0, 0);
+        }
+    };
+
+    f32x4 acc[NI][4];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+    f16x8 xa0[4], wb0[NI], xa1[4], wb1[NI];
+
+    auto read_frags = [&](const char* P, const char* Wb, int kh, int kw, int kk, f16x8* xa, f16x8* wb) {
+        const int qf = fq + 4 * kk;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int r = (wm * 4 + mi + kh) * (TW + 2) + kw + fr;
+            xa[mi] = *reinterpret_cast<const f16x8*>(P + r * 128 + ((qf ^ ((r >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int r = wn * (NI * 16) + ni * 16 + fr;
+            wb[ni] = *reinterpret_cast<const f16x8*>(Wb + r * 128 + ((qf ^ ((r >> 1) & 7)) << 4));
+        }
+    };
+    auto mfma_all = [&](const f16x8* xa, const f16x8* wb) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0);
+    };
+
+    // ---- prologue: halo 0 and the first two weight slabs, fully landed before anyone reads
+    dma_patch(0, 0);
+    dma_w(0);
+    if (total > 1) dma_w(1);
+    CY_WAIT_VM(0);
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();             // group B runs half an iteration behind
+
+    int it = 0;
+#pragma unroll 1
+    for (int ch = 0; ch < chunks; ++ch) {
+        const char* P = Pbuf + (ch & 1) * P_BYTES;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap, ++it) {
+            const char* Wb = Wbuf + (it % RING) * W_BYTES;
+            const int kh = tap / 3, kw = tap - kh * 3;
+            // -------- LOAD(it): requests two taps ahead, fragment reads of the first 32 channels
+            const bool pre_p = tap == 1 && ch + 1 < chunks, pre_w = it + 2 < total;
+            if (pre_w) dma_w(it + 2);
+            if (pre_p) dma_patch((ch + 1) & 1, ch + 1);      // issued after the slab so the halo may stay in flight
+            read_frags(P, Wb, kh, kw, 0, xa0, wb0);
+            if (pre_p) { CY_WAIT_VM(WROUNDS + PROUNDS); }    // the slab of tap it+1 (requested last iteration) has landed
+            else if (pre_w) { CY_WAIT_VM(WROUNDS); }
+            else { CY_WAIT_VM(0); }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // -------- COMPUTE(it)
+            read_frags(P, Wb, kh, kw, 1, xa1, wb1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (a.dbg & 32) __builtin_amdgcn_s_setprio(1);
+            mfma_all(xa0, wb0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_all(xa1, wb1);
+            if (a.dbg & 32) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();             // pairs with group B's last barrier
+
+    // ---- epilogue: lane owns NI*4 contiguous channels of one pixel
+    // packed weight row wn*NI*16 + ni*16 + rr holds channel 64*blk + 16*(rr>>2) + 4*ni_g + (rr&3), ni_g = (wn*NI+ni)&3
+    const int cbase = n0 + ((wn * NI) >> 2) * 64 + fq * 16 + ((wn * NI) & 3) * 4;
+    float bv[NI * 4];
+#pragma unroll
+    for (int j = 0; j < NI * 4; ++j) bv[j] = a.bias[cbase + j];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int y = y0 + wm * 4 + mi, x = x0 + fr;
+        if (y >= H || x >= W) continue;
+        const long pix = ((long)b * H + y) * W + x;
+        float v[NI * 4];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float t = acc[ni][mi][j] + bv[ni * 4 + j];
+                if (a.act) t = silu_fast(t);
+                v[ni * 4 + j] = t;
+            }
+        if (cbase + NI * 4 <= a.Cout) {
+            f16* dst = reinterpret_cast<f16*>(a.out) + pix * a.out_ct + a.out_coff + cbase;
+            if (a.res) {
+                const f16* rp = reinterpret_cast<const f16*>(a.res) + pix * a.res_ct + a.res_coff + cbase;
+#pragma unroll
+                for (int h8 = 0; h8 < NI / 2; ++h8) {
+                    const f16x8 rv = *reinterpret_cast<const f16x8*>(rp + 8 * h8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[8 * h8 + j] += (float)rv[j];
+                }
+            }
+#pragma unroll
+            for (int h8 = 0; h8 < NI / 2; ++h8) {
+                f16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (f16)v[8 * h8 + j];
+                *reinterpret_cast<f16x8*>(dst + 8 * h8) = o;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NI * 4; ++j) {
+                const int c = cbase + j;
+                if (c >= a.Cout) continue;
+                float t = v[j];
+                if (a.res) t += (float)(reinterpret_cast<const f16*>(a.res)[pix * a.res_ct + a.res_coff + c]);
+                reinterpret_cast<f16*>(a.out)[pix * a.out_ct + a.out_coff + c] = (f16)t;
+            }
+        }
+    }
+}
+
+template <int NI>
+static hipError_t launch_pp(const ConvArgs& a, hipStream_t s) {
+    constexpr int BN = 2 * NI * 16, PR = 18 * 18, NWI = (PR + 7) / 8;
+    const size_t lds = 2 * (NWI + 1) * 1024 + 4 * BN * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_pp_kernel<NI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int blocks = a.B * ((a.Hi + 15) / 16) * ((a.Wi + 15) / 16) * ((pad64(a.Cout) + BN - 1) / BN);
+    hipLaunchKernelGGL((conv3x3_pp_kernel<NI>), dim3(blocks), dim3(512), lds, s, a);
+    return hipGetLastError();
+}
+
 template <int WM, int RING>
 static hipError_t launch_halo(const ConvArgs& a, hipStream_t s) {
     constexpr int TH = 4 * WM, NT = WM * 128;
@@ -473,13 +690,14 @@ static hipError_t launch_t(const ConvArgs& a, hipStream_t s) {
 
 hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s) {
     const bool narrow = pad64(a.Cout) <= 64;
-    // 3x3 stride-1 layers with >= 128 output channels: halo-reuse kernel (fp16 context only; the fp32 parity context keeps
-    // the generic kernel).  Small maps (fewer than ~2 blocks per CU at 16-row patches) use 8-row patches.
-    if (p == PREC_F16 && a.k == 3 && a.s == 1 && a.c1 == 0 && !a.up0 && !a.out_f32 && a.Cin % 64 == 0 && !narrow &&
+    // 3x3 stride-1 layers (fp16 context; the fp32 parity context keeps the generic kernel): halo-reuse kernels.
+    //   Cout <= 64            : ping-pong kernel with 64-channel tiles (256 px x 64 ch per workgroup)
+    //   Cout >= 128           : 8x16-pixel patches x 128 channels, two workgroups per CU
+    if (p == PREC_F16 && a.k == 3 && a.s == 1 && a.c1 == 0 && !a.up0 && !a.out_f32 && a.Cin % 64 == 0 &&
         a.out_bs == a.Ho * a.Wo && a.out_ro == 0) {
-        const long blocks16 = (long)a.B * ((a.Hi + 15) / 16) * ((a.Wi + 15) / 16) * ((pad64(a.Cout) + 127) / 128);
         static const int force = getenv("CY_HALO_WM") ? atoi(getenv("CY_HALO_WM")) : 0;     // tuning override
-        if (force == 2) return launch_halo<2, 2>(a, s);
+        if (narrow) return force == 9 ? launch_t<f16, 4, 1, 2>(a, s) : launch_pp<2>(a, s);
+        if (force == 5) return launch_pp<4>(a, s);
         if (force == 4) return launch_halo<4, 2>(a, s);
         if (force == 43) return launch_halo<4, 3>(a, s);
         return launch_halo<2, 2>(a, s);

@@ -23,6 +23,7 @@ struct ConvArgs {
     const void* res; int res_ct, res_coff;             // residual source (same pixel grid) or null
     int B, Hi, Wi, Ho, Wo, Cin, Cout, k, s, act;
     uint32_t in0_bytes, in1_bytes, wgt_bytes;          // buffer extents for the hardware range check
+    int dbg;                                           // developer ablation bits (0 in production)
 };
 
 // First layer (Cin = 3 stored as 4, k=3, s=2): direct convolution.

@@ -24,6 +24,9 @@ CASES = [  # B, H, W, Cin, Cout, k, s, act, residual
     (32, 64, 64, 64, 128, 3, 1, True, False),     # halo-reuse kernel, 16-row patches
     (2, 50, 70, 128, 256, 3, 1, True, True),      # halo-reuse kernel, ragged patches + residual
     (3, 33, 17, 192, 192, 3, 1, False, False),    # halo-reuse kernel, Cout not a multiple of 128, no activation
+    (5, 40, 48, 64, 64, 3, 1, True, True),        # ping-pong kernel, 64-channel tiles, residual
+    (2, 24, 24, 256, 64, 3, 1, True, False),      # ping-pong kernel, 4 input slabs
+    (1, 16, 16, 128, 40, 3, 1, True, False),      # ping-pong kernel, ragged Cout
 ]
 
 
