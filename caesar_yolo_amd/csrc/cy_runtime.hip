@@ -26,15 +26,21 @@ struct cy_ctx {
     char* ws = nullptr; size_t ws_bytes = 0;           // activations
     std::vector<size_t> toff; std::vector<size_t> tbytes;   // per tensor, for the last forward geometry
     int lastB = 0, lastH = 0, lastW = 0;
-    // stage buffers (sized at load for max_batch)
-    void* netin = nullptr; float* pred = nullptr;
-    float* cand = nullptr; int* cand_anchor = nullptr; int* cand_count = nullptr;
-    uint64_t* keys = nullptr; uint64_t* mask = nullptr;
-    float* det = nullptr; int* det_anchor = nullptr; int* det_count = nullptr; int* merge_err = nullptr;
-    int* out_src = nullptr;
-    int* d_tiles = nullptr; double* pre_params = nullptr; double* pre_histeq = nullptr; double* pre_scratch = nullptr;
+    // stage buffers (sized at load for max_batch), two sets: cy_detect_tiles software-pipelines consecutive batches
+    // (preprocessing of batch i+1 and post-processing of batch i-1 run on side streams beside the forward of batch i)
+    struct StageBufs {
+        void* netin = nullptr; float* pred = nullptr;
+        float* cand = nullptr; int* cand_anchor = nullptr; int* cand_count = nullptr; uint64_t* keys = nullptr;
+        float* det = nullptr; int* det_anchor = nullptr; int* det_count = nullptr; int* merge_err = nullptr; int* out_src = nullptr;
+        double* pre_params = nullptr; double* pre_histeq = nullptr; double* pre_scratch = nullptr;
+    } sb[2];
+    int slot = 0;                                       // buffer set used by the stage entry points
+    StageBufs& S() { return sb[slot]; }
     size_t pre_scratch_elems = 0;
     int cap = 0, cap_pow2 = 0;
+    hipStream_t s_pre = nullptr, s_post = nullptr;      // side streams of the pipelined cy_detect_tiles
+    hipEvent_t ev_call = nullptr, ev_pre[2] = {nullptr, nullptr}, ev_fwd[2] = {nullptr, nullptr}, ev_post[2] = {nullptr, nullptr};
+    unsigned long batches = 0;                          // cy_detect_tiles calls since load / flush
     // optional per-launch timing of the forward ops (hipEvents on the caller's stream)
     bool profiling = false;
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
@@ -67,14 +73,19 @@ void free_all(cy_ctx* c) {
     c->ev_pool.clear(); c->ev_used = 0; c->prof.clear();
     for (auto& d : c->dconv) { if (d.w) hipFree(d.w); if (d.bias) hipFree(d.bias); if (d.stem_w) hipFree(d.stem_w); }
     c->dconv.clear();
-    void* ptrs[] = {c->ws, c->netin, c->pred, c->cand, c->cand_anchor, c->cand_count, c->keys, c->mask, c->det,
-                    c->det_anchor, c->det_count, c->merge_err, c->out_src, c->d_tiles, c->pre_params, c->pre_histeq,
-                    c->pre_scratch};
-    for (void* p : ptrs) if (p) hipFree(p);
-    c->ws = nullptr; c->netin = nullptr; c->pred = nullptr; c->cand = nullptr; c->cand_anchor = nullptr;
-    c->cand_count = nullptr; c->keys = nullptr; c->mask = nullptr; c->det = nullptr; c->det_anchor = nullptr;
-    c->det_count = nullptr; c->merge_err = nullptr; c->out_src = nullptr; c->d_tiles = nullptr;
-    c->pre_params = nullptr; c->pre_histeq = nullptr; c->pre_scratch = nullptr;
+    if (c->ws) hipFree(c->ws);
+    c->ws = nullptr;
+    for (auto& b : c->sb) {
+        void* ptrs[] = {b.netin, b.pred, b.cand, b.cand_anchor, b.cand_count, b.keys, b.det, b.det_anchor, b.det_count,
+                        b.merge_err, b.out_src, b.pre_params, b.pre_histeq, b.pre_scratch};
+        for (void* p : ptrs) if (p) hipFree(p);
+        b = cy_ctx::StageBufs();
+    }
+    if (c->s_pre) { hipStreamDestroy(c->s_pre); c->s_pre = nullptr; }
+    if (c->s_post) { hipStreamDestroy(c->s_post); c->s_post = nullptr; }
+    hipEvent_t* evs[] = {&c->ev_call, &c->ev_pre[0], &c->ev_pre[1], &c->ev_fwd[0], &c->ev_fwd[1], &c->ev_post[0], &c->ev_post[1]};
+    for (hipEvent_t* e : evs) if (*e) { hipEventDestroy(*e); *e = nullptr; }
+    c->batches = 0;
 }
 
 struct Reader {
@@ -146,23 +157,27 @@ int upload_weights(cy_ctx* c, const void* buf, size_t nbytes) {
     c->cap = (c->cap + 63) / 64 * 64;
     c->cap_pow2 = 1; while (c->cap_pow2 < c->cap) c->cap_pow2 <<= 1;
     const size_t Bm = g.max_batch;
-    HIPCHK(c, hipMalloc(&c->netin, Bm * g.max_h * g.max_w * 4 * es));
-    HIPCHK(c, hipMalloc(&c->pred, Bm * A * (64 + nc) * sizeof(float)));
-    HIPCHK(c, hipMalloc(&c->cand, Bm * c->cap * 6 * sizeof(float)));
-    HIPCHK(c, hipMalloc(&c->cand_anchor, Bm * c->cap * sizeof(int)));
-    HIPCHK(c, hipMalloc(&c->cand_count, Bm * sizeof(int)));
-    HIPCHK(c, hipMalloc(&c->keys, Bm * c->cap_pow2 * sizeof(uint64_t)));
-    HIPCHK(c, hipMalloc(&c->mask, Bm * (size_t)c->cap * (c->cap / 64) * sizeof(uint64_t)));
-    HIPCHK(c, hipMalloc(&c->det, Bm * CY_MAX_DET * 6 * sizeof(float)));
-    HIPCHK(c, hipMalloc(&c->det_anchor, Bm * CY_MAX_DET * sizeof(int)));
-    HIPCHK(c, hipMalloc(&c->det_count, Bm * sizeof(int)));
-    HIPCHK(c, hipMalloc(&c->merge_err, Bm * sizeof(int)));
-    HIPCHK(c, hipMalloc(&c->out_src, Bm * CY_MAX_DET * sizeof(int)));
-    HIPCHK(c, hipMalloc(&c->d_tiles, Bm * 4 * sizeof(int)));
-    HIPCHK(c, hipMalloc(&c->pre_params, Bm * 3 * CY_MAX_STAGES * 4 * sizeof(double)));
-    HIPCHK(c, hipMalloc(&c->pre_histeq, Bm * 3 * 520 * sizeof(double)));
     c->pre_scratch_elems = Bm * 3 * (size_t)g.max_h * g.max_w;
-    HIPCHK(c, hipMalloc(&c->pre_scratch, c->pre_scratch_elems * sizeof(double)));
+    for (auto& b : c->sb) {
+        HIPCHK(c, hipMalloc(&b.netin, Bm * g.max_h * g.max_w * 4 * es));
+        HIPCHK(c, hipMalloc(&b.pred, Bm * A * (64 + nc) * sizeof(float)));
+        HIPCHK(c, hipMalloc(&b.cand, Bm * c->cap * 6 * sizeof(float)));
+        HIPCHK(c, hipMalloc(&b.cand_anchor, Bm * c->cap * sizeof(int)));
+        HIPCHK(c, hipMalloc(&b.cand_count, Bm * sizeof(int)));
+        HIPCHK(c, hipMalloc(&b.keys, Bm * c->cap_pow2 * sizeof(uint64_t)));
+        HIPCHK(c, hipMalloc(&b.det, Bm * CY_MAX_DET * 6 * sizeof(float)));
+        HIPCHK(c, hipMalloc(&b.det_anchor, Bm * CY_MAX_DET * sizeof(int)));
+        HIPCHK(c, hipMalloc(&b.det_count, Bm * sizeof(int)));
+        HIPCHK(c, hipMalloc(&b.merge_err, Bm * sizeof(int)));
+        HIPCHK(c, hipMalloc(&b.out_src, Bm * CY_MAX_DET * sizeof(int)));
+        HIPCHK(c, hipMalloc(&b.pre_params, Bm * 3 * CY_MAX_STAGES * 4 * sizeof(double)));
+        HIPCHK(c, hipMalloc(&b.pre_histeq, Bm * 3 * 520 * sizeof(double)));
+        HIPCHK(c, hipMalloc(&b.pre_scratch, c->pre_scratch_elems * sizeof(double)));
+    }
+    HIPCHK(c, hipStreamCreateWithFlags(&c->s_pre, hipStreamNonBlocking));
+    HIPCHK(c, hipStreamCreateWithFlags(&c->s_post, hipStreamNonBlocking));
+    hipEvent_t* evs[] = {&c->ev_call, &c->ev_pre[0], &c->ev_pre[1], &c->ev_fwd[0], &c->ev_fwd[1], &c->ev_post[0], &c->ev_post[1]};
+    for (hipEvent_t* e : evs) HIPCHK(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
     c->loaded = true;
     return CY_OK;
 }
@@ -438,10 +453,17 @@ int cy_conv_bn_silu(cy_ctx* c, const void* d_in, int B, int Hi, int Wi, int Cin,
     return CY_OK;
 }
 
+int cy_debug_cand_counts(cy_ctx* c, int* h_out, int B) {
+    if (!c || !c->loaded || !h_out || B < 1 || B > c->cfg.max_batch) return fail(c, CY_ERR_ARG, "bad arguments");
+    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipMemcpy(h_out, c->S().cand_count, (size_t)B * sizeof(int), hipMemcpyDeviceToHost));
+    return CY_OK;
+}
+
 int cy_preproc_params(cy_ctx* c, double* h_out, int B) {
     if (!c || !c->loaded || !h_out || B < 1 || B > c->cfg.max_batch) return fail(c, CY_ERR_ARG, "bad arguments");
     HIPCHK(c, hipDeviceSynchronize());
-    HIPCHK(c, hipMemcpy(h_out, c->pre_params, (size_t)B * 3 * CY_MAX_STAGES * 4 * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(h_out, c->S().pre_params, (size_t)B * 3 * CY_MAX_STAGES * 4 * sizeof(double), hipMemcpyDeviceToHost));
     return CY_OK;
 }
 
@@ -472,12 +494,12 @@ int cy_preproc(cy_ctx* c, const float* d_mosaic, int MH, int MW, const int* h_ti
             a.prog[i].st[j] = PreStage{st.op, st.p0, st.p1, st.p2, st.flag};
         }
     }
-    a.params = c->pre_params; a.histeq = c->pre_histeq; a.status = d_status;
+    a.params = c->S().pre_params; a.histeq = c->S().pre_histeq; a.status = d_status;
     a.out = d_netin; a.out_prec = c->prec; a.H = lb.H; a.W = lb.W; a.top = lb.top; a.left = lb.left;
     a.new_h = lb.new_h; a.new_w = lb.new_w;
     const bool resize = (lb.new_h != th) || (lb.new_w != tw);
     if (resize && (size_t)B * 3 * th * tw > c->pre_scratch_elems) return fail(c, CY_ERR_ARG, "resize scratch too small");
-    a.scratch = resize ? c->pre_scratch : nullptr;
+    a.scratch = resize ? c->S().pre_scratch : nullptr;
     HIPCHK(c, launch_preproc(a, s));
     return CY_OK;
 }
@@ -504,18 +526,18 @@ int cy_decode_nms(cy_ctx* c, const float* d_pred, int B, int H, int W, int h0, i
     DecodeArgs d{};
     d.pred = d_pred; d.B = B; d.A = cy_num_anchors(H, W); d.nc = c->plan.nc; d.conf = conf;
     for (int l = 0; l < 3; ++l) { d.lvl_h[l] = H >> (3 + l); d.lvl_w[l] = W >> (3 + l); }
-    d.cand = c->cand; d.cand_anchor = c->cand_anchor; d.cand_count = c->cand_count; d.cap = c->cap;
-    HIPCHK(c, hipMemsetAsync(c->cand_count, 0, B * sizeof(int), s));
+    d.cand = c->S().cand; d.cand_anchor = c->S().cand_anchor; d.cand_count = c->S().cand_count; d.cap = c->cap;
+    HIPCHK(c, hipMemsetAsync(c->S().cand_count, 0, B * sizeof(int), s));
     HIPCHK(c, launch_decode(d, s));
     NmsArgs n{};
-    n.cand = c->cand; n.cand_anchor = c->cand_anchor; n.cand_count = c->cand_count; n.cap = c->cap; n.B = B; n.iou = iou;
+    n.cand = c->S().cand; n.cand_anchor = c->S().cand_anchor; n.cand_count = c->S().cand_count; n.cap = c->cap; n.B = B; n.iou = iou;
     n.max_det = CY_MAX_DET;
     // ultralytics scale_boxes: gain / pad from the letterboxed and original shapes
     const double gain = std::fmin((double)H / h0, (double)W / w0);
     n.gain = (float)gain;
     n.padw = py_round_half_even((W - w0 * gain) / 2 - 0.1); n.padh = py_round_half_even((H - h0 * gain) / 2 - 0.1);
     n.w0 = w0; n.h0 = h0;
-    n.det = d_det; n.det_anchor = d_det_anchor; n.det_count = d_count; n.keys = c->keys; n.mask = c->mask;
+    n.det = d_det; n.det_anchor = d_det_anchor; n.det_count = d_count; n.keys = c->S().keys; n.mask = nullptr;
     HIPCHK(c, launch_nms(n, s));
     return CY_OK;
 }
@@ -526,7 +548,7 @@ int cy_iou_merge(cy_ctx* c, const float* d_det, const int* d_count, int B, float
     if (!d_det || !d_count || !d_out || !d_out_count || B < 1 || B > c->cfg.max_batch) return fail(c, CY_ERR_ARG, "bad arguments");
     MergeArgs m{};
     m.det = d_det; m.det_count = d_count; m.B = B; m.max_det = CY_MAX_DET; m.score_thr = score_thr; m.soft = soft; m.hard = hard;
-    m.out = d_out; m.out_count = d_out_count; m.out_src = d_out_src ? d_out_src : c->out_src; m.err = c->merge_err;
+    m.out = d_out; m.out_count = d_out_count; m.out_src = d_out_src ? d_out_src : c->S().out_src; m.err = c->S().merge_err;
     HIPCHK(c, launch_iou_merge(m, (hipStream_t)stream));
     return CY_OK;
 }
@@ -534,16 +556,52 @@ int cy_iou_merge(cy_ctx* c, const float* d_det, const int* d_count, int B, float
 int cy_detect_tiles(cy_ctx* c, const float* d_mosaic, int MH, int MW, const int* h_tiles, int B, int th, int tw, int imgsz,
                     const cy_preproc_cfg* cfg, float conf, float iou, double soft, double hard,
                     float* d_out, int* d_out_count, int* d_status, void* stream) {
+    // Software pipeline over consecutive calls (batches): three streams, two buffer sets.
+    //   s_pre  : preprocessing of batch i      (waits: forward of batch i-2 has consumed this set's network input)
+    //   stream : forward of batch i            (waits: preprocessing i; post-processing i-2 has consumed this set's head output)
+    //   s_post : decode/NMS/IoU-merge of batch i (waits: forward i)
+    // so the latency-bound statistics / NMS / merge kernels (a few dozen workgroups) run beside the conv stack of the
+    // neighbouring batches instead of serialising with it.  Outputs are complete after cy_detect_flush(ctx, stream).
     if (!c || !c->loaded) return fail(c, CY_ERR_STATE, "weights not loaded");
     cy_letterbox lb;
     if (cy_letterbox_geometry(th, tw, imgsz, &lb)) return fail(c, CY_ERR_ARG, "bad tile/imgsz");
-    int rc = cy_preproc(c, d_mosaic, MH, MW, h_tiles, B, th, tw, imgsz, cfg, c->netin, d_status, stream);
-    if (rc) return rc;
-    rc = cy_forward(c, c->netin, B, lb.H, lb.W, c->pred, stream);
-    if (rc) return rc;
-    rc = cy_decode_nms(c, c->pred, B, lb.H, lb.W, th, tw, conf, iou, c->det, c->det_anchor, c->det_count, stream);
-    if (rc) return rc;
-    return cy_iou_merge(c, c->det, c->det_count, B, conf, soft, hard, d_out, d_out_count, nullptr, stream);
+    hipStream_t sm = (hipStream_t)stream;
+    const int sl = (int)(c->batches & 1);
+    const bool reuse = c->batches >= 2;
+    c->slot = sl;
+    int rc = CY_OK;
+    // order the side streams after whatever the caller already queued on `stream` (e.g. cy_mosaic_prepare)
+    HIPCHK(c, hipEventRecord(c->ev_call, sm));
+    HIPCHK(c, hipStreamWaitEvent(c->s_pre, c->ev_call, 0));
+    if (reuse) HIPCHK(c, hipStreamWaitEvent(c->s_pre, c->ev_fwd[sl], 0));
+    rc = cy_preproc(c, d_mosaic, MH, MW, h_tiles, B, th, tw, imgsz, cfg, c->S().netin, d_status, c->s_pre);
+    if (rc) { c->slot = 0; return rc; }
+    HIPCHK(c, hipEventRecord(c->ev_pre[sl], c->s_pre));
+    HIPCHK(c, hipStreamWaitEvent(sm, c->ev_pre[sl], 0));
+    if (reuse) HIPCHK(c, hipStreamWaitEvent(sm, c->ev_post[sl], 0));
+    rc = cy_forward(c, c->S().netin, B, lb.H, lb.W, c->S().pred, sm);
+    if (rc) { c->slot = 0; return rc; }
+    HIPCHK(c, hipEventRecord(c->ev_fwd[sl], sm));
+    HIPCHK(c, hipStreamWaitEvent(c->s_post, c->ev_fwd[sl], 0));
+    rc = cy_decode_nms(c, c->S().pred, B, lb.H, lb.W, th, tw, conf, iou, c->S().det, c->S().det_anchor, c->S().det_count, c->s_post);
+    if (!rc) rc = cy_iou_merge(c, c->S().det, c->S().det_count, B, conf, soft, hard, d_out, d_out_count, nullptr, c->s_post);
+    if (rc) { c->slot = 0; return rc; }
+    HIPCHK(c, hipEventRecord(c->ev_post[sl], c->s_post));
+    c->batches++;
+    c->slot = 0;
+    return CY_OK;
+}
+
+int cy_detect_flush(cy_ctx* c, void* stream) {
+    if (!c || !c->loaded) return fail(c, CY_ERR_STATE, "weights not loaded");
+    hipStream_t sm = (hipStream_t)stream;
+    const unsigned long n = c->batches < 2 ? c->batches : 2;
+    for (unsigned long k = 0; k < n; ++k) {
+        const int sl = (int)((c->batches - 1 - k) & 1);
+        HIPCHK(c, hipStreamWaitEvent(sm, c->ev_post[sl], 0));
+        HIPCHK(c, hipStreamWaitEvent(sm, c->ev_pre[sl], 0));
+    }
+    return CY_OK;
 }
 
 }  // extern "C"

@@ -57,30 +57,36 @@ class TileEngine(object):
         dev = detector.tdev
         # fixed-capacity record buffer: [tile][300*6 floats | count | status | tile id]
         self.rec = torch.zeros((self.cap_tiles, L.CY_MAX_DET * 6 + 3), dtype=torch.float32, device=dev)
-        self.det_buf = torch.empty((self.batch, L.CY_MAX_DET, 6), dtype=torch.float32, device=dev)
-        self.cnt_buf = torch.empty((self.batch,), dtype=torch.int32, device=dev)
-        self.st_buf = torch.empty((self.batch,), dtype=torch.int32, device=dev)
+        # per-tile outputs of this rank, in processing order (each batch writes its own slice: batches overlap)
+        self.det_all = torch.zeros((max(n_my, 1), L.CY_MAX_DET, 6), dtype=torch.float32, device=dev)
+        self.cnt_all = torch.zeros((max(n_my, 1),), dtype=torch.int32, device=dev)
+        self.st_all = torch.zeros((max(n_my, 1),), dtype=torch.int32, device=dev)
+        order = [t for tids in self.my.values() for t in tids]
+        self.tid_all = torch.tensor(order if order else [0], dtype=torch.float32, device=dev)
         self.n_my = n_my
         self.gathered = None
 
     def run_local(self):
-        """Enqueue every batch of this rank's tiles; results stay on device in self.rec."""
+        """Enqueue every batch of this rank's tiles (software-pipelined inside the library); results stay on device."""
         row = 0
-        self.rec.zero_()
         for (th, tw), tids in self.my.items():
             for i in range(0, len(tids), self.batch):
                 chunk = tids[i:i + self.batch]
                 B = len(chunk)
                 xy = [(self.grid[t][0], self.grid[t][2]) for t in chunk]
-                out = (self.det_buf[:B], self.cnt_buf[:B], self.st_buf[:B])
+                out = (self.det_all[row:row + B], self.cnt_all[row:row + B], self.st_all[row:row + B])
                 self.det.detect_tiles(self.mosaic, xy, th, tw, self.imgsz, self.pre_cfg, self.conf, self.iou,
-                                      self.soft, self.hard, out=out)
-                r = self.rec[row:row + B]
-                r[:, :L.CY_MAX_DET * 6] = self.det_buf[:B].reshape(B, -1)
-                r[:, -3] = self.cnt_buf[:B].float()
-                r[:, -2] = self.st_buf[:B].float()
-                r[:, -1] = torch.tensor(chunk, dtype=torch.float32, device=r.device)
+                                      self.soft, self.hard, out=out, flush=False)
                 row += B
+        if hasattr(self.det, "flush"):
+            self.det.flush()
+        n = self.n_my
+        self.rec.zero_()
+        if n:
+            self.rec[:n, :L.CY_MAX_DET * 6] = self.det_all[:n].reshape(n, -1)
+            self.rec[:n, -3] = self.cnt_all[:n].float()
+            self.rec[:n, -2] = self.st_all[:n].float()
+            self.rec[:n, -1] = self.tid_all[:n]
         return row
 
     def gather(self):

@@ -160,8 +160,13 @@ class HipDetector(object):
                                         self._p(ocnt), self._p(osrc), self._stream()))
         return out, ocnt, osrc
 
-    def detect_tiles(self, mosaic, tiles_xy, th, tw, imgsz, cfg, conf, iou, soft, hard, out=None):
-        """Whole per-tile path for B same-shape tiles.  Returns (det [B,300,6], count [B], status [B]) on device."""
+    def flush(self):
+        """Order the current stream behind every batch queued by detect_tiles (they run on internal side streams)."""
+        self._chk(self.lib.cy_detect_flush(self.ctx, self._stream()))
+
+    def detect_tiles(self, mosaic, tiles_xy, th, tw, imgsz, cfg, conf, iou, soft, hard, out=None, flush=True):
+        """Whole per-tile path for B same-shape tiles.  Returns (det [B,300,6], count [B], status [B]) on device.
+        With flush=False consecutive calls overlap (give each its own `out` buffers and call flush() before reading)."""
         B = len(tiles_xy)
         if out is None:
             det = torch.empty((B, L.CY_MAX_DET, 6), dtype=torch.float32, device=self.tdev)
@@ -173,6 +178,8 @@ class HipDetector(object):
         self._chk(self.lib.cy_detect_tiles(self.ctx, self._p(mosaic), mosaic.shape[0], mosaic.shape[1], t, B, th, tw,
                                            imgsz, C.byref(cfg), conf, iou, soft, hard, self._p(det), self._p(cnt),
                                            self._p(status), self._stream()))
+        if flush:
+            self.flush()
         return det, cnt, status
 
     def conv_bn_silu(self, x_nhwc, w, b, k, s, act=True, res=None):

@@ -110,15 +110,23 @@ int cy_debug_read_conv(cy_ctx* ctx, const char* conv_name, float* h_out, size_t 
 int cy_decode_nms(cy_ctx* ctx, const float* d_pred, int B, int H, int W, int h0, int w0, float conf, float iou,
                   float* d_det, int* d_det_anchor, int* d_count, void* stream);
 
+/* number of pre-NMS candidates per tile of the last cy_decode_nms call (diagnostics) */
+int cy_debug_cand_counts(cy_ctx* ctx, int* h_out, int B);
+
 /* Analyzer.process_detections (caesar_yolo/evaluation.py:252-346): score re-filter, IoU graph, connected components,
  * best score per component.  d_out [B][300][6], d_out_count [B], d_out_src [B][300] = row of d_det kept */
 int cy_iou_merge(cy_ctx* ctx, const float* d_det, const int* d_count, int B, float score_thr, double thr_soft,
                  double thr_hard, float* d_out, int* d_out_count, int* d_out_src, void* stream);
 
-/* the whole per-tile path for B same-shape tiles; status/det/count as above (merged detections in tile pixels) */
+/* the whole per-tile path for B same-shape tiles; status/det/count as above (merged detections in tile pixels).
+ * Consecutive calls are software-pipelined on internal side streams (preprocessing / post-processing of neighbouring
+ * batches overlap the forward pass): give every in-flight call its own output buffers and call cy_detect_flush before
+ * reading them -- after it, work queued on `stream` is ordered behind all outstanding batches */
 int cy_detect_tiles(cy_ctx* ctx, const float* d_mosaic, int MH, int MW, const int* h_tiles, int B, int th, int tw,
                     int imgsz, const cy_preproc_cfg* cfg, float conf, float iou, double thr_soft, double thr_hard,
                     float* d_out, int* d_out_count, int* d_status, void* stream);
+
+int cy_detect_flush(cy_ctx* ctx, void* stream);
 
 /* single fused Conv+bias+SiLU layer on caller tensors (kernel-level parity tests).
  * d_in [B][Hi][Wi][Cin], d_out [B][Ho][Wo][Cout] in the context precision; h_w [Cout][Cin][k][k], h_b [Cout] fp32;

@@ -26,7 +26,7 @@ class ReplayDetector(object):
         self.by_origin = {(t[0], t[2]): i for i, t in enumerate(fx["grid"])}
         self.skipped = {c[0] for c in fx["calls"] if c[1] < 0}
 
-    def detect_tiles(self, mosaic, xy, th, tw, imgsz, cfg, conf, iou, soft, hard, out=None):
+    def detect_tiles(self, mosaic, xy, th, tw, imgsz, cfg, conf, iou, soft, hard, out=None, flush=True):
         det, cnt, status = out
         det.zero_()
         for b, o in enumerate(xy):
