@@ -159,7 +159,8 @@ def main():
             "conv_stack_mfma_frac_whole_job": value * FLOP_PER_TILE_512 / 1e12 / (PEAK_FP16_DENSE_TFLOPS * world),
         }
         if prof:
-            k = prof[0]                      # dominant kernel: the 128x128-tile implicit-GEMM conv
+            prof = [p for p in prof if p["launches"]]
+            k = max(prof, key=lambda p: p["ms"])          # dominant kernel = largest share of GPU time in the forward
             if k["launches"] and k["ms"] > 0:
                 ach = k["flops"] / (k["ms"] * 1e-3) / 1e12
                 out["roofline"] = {"kernel": k["kernel"], "bound": "mfma", "achieved": ach, "peak": PEAK_FP16_DENSE_TFLOPS,

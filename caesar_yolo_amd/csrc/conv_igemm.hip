@@ -688,22 +688,38 @@ static hipError_t launch_t(const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s) {
+// Kernel variants (also the keys of the profiling summary)
+static const char* const kVariantNames[CONV_NUM_VARIANTS] = {
+    "conv_igemm_kernel<2,2,4> generic 128x128", "conv_igemm_kernel<4,1,2> generic 128x64",
+    "conv3x3_halo_kernel<2,2> 3x3 s1 8x16px x128ch", "conv3x3_pp_kernel<2> 3x3 s1 16x16px x64ch",
+    "conv3x3_pp_kernel<4> 3x3 s1 16x16px x128ch", "conv3x3_halo_kernel<4,*> 3x3 s1 16x16px x128ch"};
+const char* conv_variant_name(int v) { return v >= 0 && v < CONV_NUM_VARIANTS ? kVariantNames[v] : "?"; }
+
+int conv_variant(Precision p, const ConvArgs& a) {
     const bool narrow = pad64(a.Cout) <= 64;
     // 3x3 stride-1 layers (fp16 context; the fp32 parity context keeps the generic kernel): halo-reuse kernels.
-    //   Cout <= 64            : ping-pong kernel with 64-channel tiles (256 px x 64 ch per workgroup)
-    //   Cout >= 128           : 8x16-pixel patches x 128 channels, two workgroups per CU
+    //   Cout <= 64  : ping-pong kernel with 64-channel tiles (256 px x 64 ch per workgroup)
+    //   Cout >= 128 : 8x16-pixel patches x 128 channels, two workgroups per CU
     if (p == PREC_F16 && a.k == 3 && a.s == 1 && a.c1 == 0 && !a.up0 && !a.out_f32 && a.Cin % 64 == 0 &&
         a.out_bs == a.Ho * a.Wo && a.out_ro == 0) {
         static const int force = getenv("CY_HALO_WM") ? atoi(getenv("CY_HALO_WM")) : 0;     // tuning override
-        if (narrow) return force == 9 ? launch_t<f16, 4, 1, 2>(a, s) : launch_pp<2>(a, s);
-        if (force == 5) return launch_pp<4>(a, s);
-        if (force == 4) return launch_halo<4, 2>(a, s);
-        if (force == 43) return launch_halo<4, 3>(a, s);
-        return launch_halo<2, 2>(a, s);
+        if (narrow) return force == 9 ? CONV_GENERIC_64 : CONV_PP_64;
+        if (force == 5) return CONV_PP_128;
+        if (force == 4 || force == 43) return CONV_HALO16_128;
+        return CONV_HALO8_128;
     }
-    if (p == PREC_F16) return narrow ? launch_t<f16, 4, 1, 2>(a, s) : launch_t<f16, 2, 2, 4>(a, s);
-    return narrow ? launch_t<float, 4, 1, 2>(a, s) : launch_t<float, 2, 2, 4>(a, s);
+    return narrow ? CONV_GENERIC_64 : CONV_GENERIC_128;
+}
+
+hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s) {
+    switch (conv_variant(p, a)) {
+        case CONV_PP_64: return launch_pp<2>(a, s);
+        case CONV_PP_128: { ConvArgs b2 = a; b2.dbg = getenv("CY_DBG") ? atoi(getenv("CY_DBG")) : 0; return launch_pp<4>(b2, s); }
+        case CONV_HALO16_128: return (getenv("CY_HALO_WM") && atoi(getenv("CY_HALO_WM")) == 43) ? launch_halo<4, 3>(a, s) : launch_halo<4, 2>(a, s);
+        case CONV_HALO8_128: return launch_halo<2, 2>(a, s);
+        case CONV_GENERIC_64: return p == PREC_F16 ? launch_t<f16, 4, 1, 2>(a, s) : launch_t<float, 4, 1, 2>(a, s);
+        default: return p == PREC_F16 ? launch_t<f16, 2, 2, 4>(a, s) : launch_t<float, 2, 2, 4>(a, s);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ weights
@@ -774,13 +790,89 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemArgs a) {
     }
 }
 
+// fp16 context: the stem as a K=32 (27 padded) MFMA GEMM.  A wave turns 16 output pixels x 64 channels per step:
+// the 64x32 weight panel lives in registers for the whole kernel (A operand), each lane gathers the 8 im2col values of
+// its (pixel, k-chunk) from the NHWC4 image with the halo zeroed, and stores 16 contiguous channels of its pixel.
+// Bound by the 64-channel output write (8 MB per 512x512 tile), not by arithmetic.
+__global__ __launch_bounds__(256) void stem_mfma_kernel(const StemArgs a, const f16* __restrict__ wpk) {
+    const int lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4;
+    f16x8 wb[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) wb[ni] = *reinterpret_cast<const f16x8*>(wpk + (ni * 16 + fr) * 32 + fq * 8);
+    float bv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) bv[j] = a.bias[fq * 16 + j];
+    // k = 8*fq + j  ->  tap = k/3 (kh = tap/3, kw = tap%3), channel = k%3; k >= 27 is zero padding
+    int dh[8], dw[8], dc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 8 * fq + j, tap = k / 3;
+        dh[j] = tap / 3 - 1; dw[j] = tap % 3 - 1; dc[j] = k < 27 ? k % 3 : -1;
+    }
+    const long ngroups = ((long)a.B * a.Ho * a.Wo + 15) / 16;
+    const long npix = (long)a.B * a.Ho * a.Wo;
+    const long wave_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+    const f16* in = reinterpret_cast<const f16*>(a.in);
+    for (long g = wave_id; g < ngroups; g += nwaves) {
+        const long pix = g * 16 + fr;
+        const bool pv = pix < npix;
+        const int wo = (int)(pix % a.Wo), ho = (int)((pix / a.Wo) % a.Ho), b = (int)(pix / ((long)a.Wo * a.Ho));
+        f16x8 xa;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int hi = 2 * ho + dh[j], wi = 2 * wo + dw[j];
+            const bool ok = pv && dc[j] >= 0 && (unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi;
+            xa[j] = ok ? in[(((long)b * a.Hi + hi) * a.Wi + wi) * 4 + dc[j]] : (f16)0.0f;
+        }
+        f32x4 acc[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            acc[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ni], xa, acc[ni], 0, 0, 0);
+        }
+        if (pv) {
+            f16x8 o0, o1;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = silu_fast(acc[ni][j] + bv[ni * 4 + j]);
+                    if (ni < 2) o0[ni * 4 + j] = (f16)v; else o1[(ni - 2) * 4 + j] = (f16)v;
+                }
+            f16* dst = reinterpret_cast<f16*>(a.out) + pix * a.out_ct + a.out_coff + fq * 16;
+            *reinterpret_cast<f16x8*>(dst) = o0;
+            *reinterpret_cast<f16x8*>(dst + 8) = o1;
+        }
+    }
+}
+
 hipError_t launch_stem(Precision p, const StemArgs& a, hipStream_t s) {
     if (a.Cout > 64 || a.Cout % 16) return hipErrorInvalidValue;
+    if (p == PREC_F16 && a.Cout == 64 && a.wpk) {
+        const long ngroups = ((long)a.B * a.Ho * a.Wo + 15) / 16;
+        const int grid = (int)((ngroups + 3) / 4 < 4096 ? (ngroups + 3) / 4 : 4096);
+        hipLaunchKernelGGL(stem_mfma_kernel, dim3(grid), dim3(256), 0, s, a, reinterpret_cast<const f16*>(a.wpk));
+        return hipGetLastError();
+    }
     const long total = (long)a.B * a.Ho * a.Wo * (a.Cout / 16);
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     if (p == PREC_F16) hipLaunchKernelGGL(stem_kernel<f16>, dim3(grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(stem_kernel<float>, dim3(grid), dim3(256), 0, s, a);
     return hipGetLastError();
+}
+
+// packed stem weights for stem_mfma_kernel: [64 rows, permuted like pack_weights][32] fp16, k = (kh*3+kw)*3 + c
+void pack_stem_weights(const float* W, int cout, void* dst) {
+    f16* o = reinterpret_cast<f16*>(dst);
+    for (int row = 0; row < 64; ++row) {
+        const int ni = (row >> 4) & 3, rr = row & 15;
+        const int n = (rr >> 2) * 16 + ni * 4 + (rr & 3);
+        for (int k = 0; k < 32; ++k) {
+            float v = 0.0f;
+            if (n < cout && k < 27) { const int tap = k / 3, c = k % 3; v = W[((size_t)n * 3 + c) * 9 + tap]; }
+            o[row * 32 + k] = (f16)v;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ SPPF pool

@@ -29,6 +29,7 @@ struct ConvArgs {
 // First layer (Cin = 3 stored as 4, k=3, s=2): direct convolution.
 struct StemArgs {
     const void* in; void* out; const float* w; const float* bias;   // w: [27][Cout] fp32 (tap-major, then c)
+    const void* wpk;                                                // fp16 context: [64][32] packed panel (pack_stem_weights)
     int B, Hi, Wi, Ho, Wo, Cout, out_ct, out_coff;
 };
 
@@ -37,6 +38,9 @@ struct PoolArgs {   // MaxPool2d(5,1,2) on a channel slice of an NHWC buffer, -i
 };
 
 hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s);
+enum ConvVariant { CONV_GENERIC_128 = 0, CONV_GENERIC_64, CONV_HALO8_128, CONV_PP_64, CONV_PP_128, CONV_HALO16_128, CONV_NUM_VARIANTS };
+int conv_variant(Precision p, const ConvArgs& a);          // which kernel launch_conv picks
+const char* conv_variant_name(int v);
 hipError_t launch_stem(Precision p, const StemArgs& a, hipStream_t s);
 hipError_t launch_pool5(Precision p, const PoolArgs& a, hipStream_t s);
 
@@ -45,6 +49,7 @@ hipError_t launch_pool5(Precision p, const PoolArgs& a, hipStream_t s);
 //   so that MFMA row (ni, rr) holds channel 64*blk + 16*(rr>>2) + 4*ni + (rr&3).
 size_t packed_weight_bytes(Precision p, int cout, int cin, int k);
 void pack_weights(Precision p, const float* W, int cout, int cin, int k, void* dst);
+void pack_stem_weights(const float* W, int cout, void* dst);      // 64*32 fp16
 __host__ __device__ inline int pad64(int c) { return (c + 63) / 64 * 64; }
 
 // ---- detection post-processing --------------------------------------------------------------

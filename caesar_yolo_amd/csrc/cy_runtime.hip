@@ -134,6 +134,12 @@ int upload_weights(cy_ctx* c, const void* buf, size_t nbytes) {
                 sw[(size_t)(t * 3 + cch) * co + o] = W[((size_t)o * 3 + cch) * 9 + t];
             HIPCHK(c, hipMalloc(&dc.stem_w, 4 * sw.size()));
             HIPCHK(c, hipMemcpy(dc.stem_w, sw.data(), 4 * sw.size(), hipMemcpyHostToDevice));
+            if (c->prec == PREC_F16 && co == 64) {
+                std::vector<char> pk(64 * 32 * 2);
+                pack_stem_weights(W, (int)co, pk.data());
+                HIPCHK(c, hipMalloc(&dc.w, pk.size()));
+                HIPCHK(c, hipMemcpy(dc.w, pk.data(), pk.size(), hipMemcpyHostToDevice));
+            }
             continue;
         }
         if (ci % 8) return fail(c, CY_ERR_UNSUPPORTED, "conv input channels must be a multiple of 8: " + name);
@@ -316,18 +322,18 @@ int cy_forward(cy_ctx* c, const void* d_netin, int B, int H, int W, float* d_pre
         if (o.kind == OPK_STEM) {
             const Tensor& ti = p.tensors[o.in0]; const Tensor& to = p.tensors[o.out];
             StemArgs a{};
-            a.in = tptr(o.in0); a.out = tptr(o.out); a.w = c->dconv[o.conv].stem_w; a.bias = c->dconv[o.conv].bias;
+            a.in = tptr(o.in0); a.out = tptr(o.out); a.w = c->dconv[o.conv].stem_w; a.bias = c->dconv[o.conv].bias; a.wpk = c->dconv[o.conv].w;
             a.B = B; a.Hi = H >> ti.level; a.Wi = W >> ti.level; a.Ho = H >> to.level; a.Wo = W >> to.level;
             a.Cout = p.convs[o.conv].cout; a.out_ct = to.C; a.out_coff = o.out_coff;
             HIPCHK(c, launch_stem(c->prec, a, s));
-            prof_done(2, 2.0 * B * a.Ho * a.Wo * a.Cout * 27.0);
+            prof_done(CONV_NUM_VARIANTS, 2.0 * B * a.Ho * a.Wo * a.Cout * 27.0);
         } else if (o.kind == OPK_POOL) {
             const Tensor& t = p.tensors[o.in0];
             PoolArgs a{};
             a.src = tptr(o.in0); a.dst = tptr(o.out); a.ct = t.C; a.src_coff = o.in0_coff; a.dst_coff = o.out_coff;
             a.C = o.c0; a.B = B; a.H = H >> t.level; a.W = W >> t.level;
             HIPCHK(c, launch_pool5(c->prec, a, s));
-            prof_done(3, 0.0);
+            prof_done(CONV_NUM_VARIANTS + 1, 0.0);
         } else {
             const ConvDesc& d = p.convs[o.conv];
             ConvArgs a{};
@@ -352,7 +358,7 @@ int cy_forward(cy_ctx* c, const void* d_netin, int B, int H, int W, float* d_pre
             }
             if (o.res >= 0) { a.res = tptr(o.res); a.res_ct = p.tensors[o.res].C; a.res_coff = o.res_coff; }
             HIPCHK(c, launch_conv(c->prec, a, s));
-            prof_done(pad64(a.Cout) <= 64 ? 1 : 0, 2.0 * B * a.Ho * a.Wo * (double)a.Cout * a.Cin * a.k * a.k);
+            prof_done(conv_variant(c->prec, a), 2.0 * B * a.Ho * a.Wo * (double)a.Cout * a.Cin * a.k * a.k);
         }
     }
     return CY_OK;
@@ -366,17 +372,21 @@ int cy_profile_enable(cy_ctx* c, int on) {
 }
 
 int cy_profile_summary(cy_ctx* c, cy_prof_entry* out, int cap) {
-    // kinds: 0 conv_igemm 128x128 tile, 1 conv_igemm 128x64 tile, 2 stem, 3 pool5
-    if (!c || !out || cap < 4) return fail(c, CY_ERR_ARG, "bad arguments");
+    // one entry per forward kernel variant (conv variants in ConvVariant order, then stem, pool)
+    const int n = CONV_NUM_VARIANTS + 2;
+    if (!c || !out || cap < n) return fail(c, CY_ERR_ARG, "bad arguments");
     HIPCHK(c, hipDeviceSynchronize());
-    const char* nm[4] = {"conv_igemm_kernel<2,2,4> (128x128)", "conv_igemm_kernel<4,1,2> (128x64)", "stem_kernel", "pool5_kernel"};
-    for (int k = 0; k < 4; ++k) { memset(&out[k], 0, sizeof(out[k])); strncpy(out[k].kernel, nm[k], sizeof(out[k].kernel) - 1); }
+    for (int k = 0; k < n; ++k) {
+        memset(&out[k], 0, sizeof(out[k]));
+        const char* nm = k < CONV_NUM_VARIANTS ? conv_variant_name(k) : (k == CONV_NUM_VARIANTS ? "stem_kernel" : "pool5_kernel");
+        strncpy(out[k].kernel, nm, sizeof(out[k].kernel) - 1);
+    }
     for (const auto& r : c->prof) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, c->ev_pool[r.e0], c->ev_pool[r.e1]) != hipSuccess) continue;
         out[r.kind].ms += ms; out[r.kind].flops += r.flops; out[r.kind].launches += 1;
     }
-    return 4;
+    return n;
 }
 
 int cy_profile_layers(cy_ctx* c, cy_prof_entry* out, int cap) {

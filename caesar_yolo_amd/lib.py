@@ -49,7 +49,7 @@ class cy_conv_desc(C.Structure):
 
 
 class cy_prof_entry(C.Structure):
-    _fields_ = [("kernel", C.c_char * 48), ("ms", C.c_double), ("flops", C.c_double), ("launches", C.c_long)]
+    _fields_ = [("kernel", C.c_char * 64), ("ms", C.c_double), ("flops", C.c_double), ("launches", C.c_long)]
 
 
 class cy_letterbox(C.Structure):

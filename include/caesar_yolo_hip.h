@@ -96,9 +96,9 @@ int cy_letterbox_pack(cy_ctx* ctx, const double* d_planes, int B, int h0, int w0
 /* DetectionModel.forward: d_netin [B][H][W][4] -> d_pred [B][A][64+nc] fp32 raw head output */
 int cy_forward(cy_ctx* ctx, const void* d_netin, int B, int H, int W, float* d_pred, void* stream);
 /* per-launch timing of the forward kernels with hipEvents on the caller's stream (bench.py roofline): enable, run
- * cy_forward / cy_detect_tiles as usual, then read the totals per kernel (entries: both conv_igemm tile variants,
+ * cy_forward / cy_detect_tiles as usual, then read the totals per kernel variant (up to 8 entries: the conv variants,
  * stem, pool); flops are the ALGORITHMIC 2*MACs of the launches timed */
-typedef struct cy_prof_entry { char kernel[48]; double ms; double flops; long launches; } cy_prof_entry;
+typedef struct cy_prof_entry { char kernel[64]; double ms; double flops; long launches; } cy_prof_entry;
 int cy_profile_enable(cy_ctx* ctx, int on);
 int cy_profile_summary(cy_ctx* ctx, cy_prof_entry* out, int cap);
 int cy_profile_layers(cy_ctx* ctx, cy_prof_entry* out, int cap);    /* the same, one entry per convolution (graph order) */
