@@ -657,6 +657,161 @@ static hipError_t launch_pp(const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ 3x3 s1, Cin = 64: persistent
+// The six bottleneck convolutions of the full-resolution C2f (64 -> 64 channels over 1M pixels per 64-tile batch) have
+// only nine K-slabs per output patch, so a one-patch-per-workgroup kernel spends most of its time in prologue/epilogue
+// (measured: 16 rounds x ~10 us).  Here a workgroup is persistent: the whole 64 x (9 x 64) weight panel is staged in LDS
+// ONCE (72 KB), next to a double-buffered input halo (2 x 42 KB), and the nine taps of a patch run without any barrier; the halo of the next patch streams in (LDS-DMA) under the current patch's MFMAs and
+// stores.  One barrier per patch.
+__global__ __launch_bounds__(256) void conv3x3_c64_kernel(const ConvArgs a) {
+    constexpr int TH = 16, TW = 16, NW = 4, NI = 4;      // 4 waves, one per SIMD, each 64 px x 64 ch with the full register file
+    constexpr int PR = (TH + 2) * (TW + 2), NWI = (PR + 7) / 8, PROUNDS = (NWI + NW - 1) / NW;
+    constexpr int P_BYTES = (NWI + 1) * 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void lds_void;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int H = a.Hi, W = a.Wi;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int npatch = a.B * tiles_y * tiles_x;
+    const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in0), 0, a.in0_bytes, 0x00020000);
+
+    // ---- weights -> LDS once: [tap][64 rows][128 B], same source-side swizzle as every other tile image
+    constexpr int W_BYTES = 9 * 64 * 128;
+    char* const Wl = smem;
+    char* const Pl = smem + W_BYTES;
+    {
+        const auto rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wgt), 0, a.wgt_bytes, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 18; ++j) {
+            const int pc = j * NW + wave;                   // 72 pieces of 8 rows: piece = tap*8 + row block
+            const int tap = pc >> 3, row = (pc & 7) * 8 + (lane >> 3);
+            const int q = (lane & 7) ^ ((row >> 1) & 7);
+            const unsigned off = (unsigned)((row * 9 + tap) * 64 + q * 8) * 2u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)(Wl + pc * 1024), 16, off, 0, 0, 0);
+        }
+    }
+    const int cbase = fq * 16;                             // 16 contiguous channels per lane
+    float bv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) bv[j] = a.bias[cbase + j];
+
+    auto dma_patch = [&](int buf, int pidx) {
+        const int tx = pidx % tiles_x, ty = (pidx / tiles_x) % tiles_y, b = pidx / (tiles_x * tiles_y);
+        const int y0 = ty * TH, x0 = tx * TW;
+#pragma unroll
+        for (int j = 0; j < PROUNDS; ++j) {
+            const int wi = j * NW + wave;
+            const int r = wi * 8 + (lane >> 3);
+            const int ry = r / (TW + 2), rx = r - ry * (TW + 2);
+            const int y = y0 + ry - 1, x = x0 + rx - 1;
+            const int q = (lane & 7) ^ ((r >> 1) & 7);
+            const bool ok = r < PR && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+            const unsigned off = ok ? (unsigned)(((b * H + y) * W + x) * a.in0_ct + a.in0_coff + q * 8) * 2u : CY_OOB;
+            char* dst = Pl + buf * P_BYTES + (wi < NWI ? wi : NWI) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_void*)dst, 16, off, 0, 0, 0);
+        }
+    };
+
+    int pidx = blockIdx.x;
+    if (pidx < npatch) dma_patch(0, pidx);
+    CY_WAIT_VM(0);
+    __builtin_amdgcn_s_barrier();
+    int it = 0;
+    for (; pidx < npatch; pidx += gridDim.x, ++it) {
+        const int nxt = pidx + gridDim.x;
+        if (nxt < npatch) dma_patch((it + 1) & 1, nxt);
+        const char* P = Pl + (it & 1) * P_BYTES;
+        f32x4 acc[NI][4];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int kh = tap / 3, kw = tap - kh * 3;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int qf = fq + 4 * kk;
+                f16x8 xa[4], wb[NI];
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    const int r = (wm * 4 + mi + kh) * (TW + 2) + kw + fr;
+                    xa[mi] = *reinterpret_cast<const f16x8*>(P + r * 128 + ((qf ^ ((r >> 1) & 7)) << 4));
+                }
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    wb[ni] = *reinterpret_cast<const f16x8*>(Wl + (tap * 64 + ni * 16 + fr) * 128 + ((qf ^ ((fr >> 1) & 7)) << 4));
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0);
+            }
+        }
+        // ---- epilogue of this patch
+        const int tx = pidx % tiles_x, ty = (pidx / tiles_x) % tiles_y, b = pidx / (tiles_x * tiles_y);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int y = ty * TH + wm * 4 + mi, x = tx * TW + fr;
+            if (y >= H || x >= W) continue;
+            const long pix = ((long)b * H + y) * W + x;
+            float v[16];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float t = acc[ni][mi][j] + bv[ni * 4 + j];
+                    if (a.act) t = silu_fast(t);
+                    v[ni * 4 + j] = t;
+                }
+            if (cbase + 16 <= a.Cout) {
+                f16* dst = reinterpret_cast<f16*>(a.out) + pix * a.out_ct + a.out_coff + cbase;
+                if (a.res) {
+                    const f16* rp = reinterpret_cast<const f16*>(a.res) + pix * a.res_ct + a.res_coff + cbase;
+                    const f16x8 r0v = *reinterpret_cast<const f16x8*>(rp), r1v = *reinterpret_cast<const f16x8*>(rp + 8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { v[j] += (float)r0v[j]; v[8 + j] += (float)r1v[j]; }
+                }
+                f16x8 o0, o1;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { o0[j] = (f16)v[j]; o1[j] = (f16)v[8 + j]; }
+                *reinterpret_cast<f16x8*>(dst) = o0;
+                *reinterpret_cast<f16x8*>(dst + 8) = o1;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int c = cbase + j;
+                    if (c >= a.Cout) continue;
+                    float t = v[j];
+                    if (a.res) t += (float)(reinterpret_cast<const f16*>(a.res)[pix * a.res_ct + a.res_coff + c]);
+                    reinterpret_cast<f16*>(a.out)[pix * a.out_ct + a.out_coff + c] = (f16)t;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        CY_WAIT_VM(0);                                       // next halo landed (and this patch's stores retired)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
+static hipError_t launch_c64(const ConvArgs& a, hipStream_t s) {
+    constexpr int NWI = (18 * 18 + 7) / 8;
+    const size_t lds = 9 * 64 * 128 + 2 * (NWI + 1) * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int npatch = a.B * ((a.Hi + 15) / 16) * ((a.Wi + 15) / 16);
+    const int grid = npatch < 256 ? npatch : 256;                                  // one persistent workgroup per CU
+    hipLaunchKernelGGL(conv3x3_c64_kernel, dim3(grid), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
 template <int WM, int RING>
 static hipError_t launch_halo(const ConvArgs& a, hipStream_t s) {
     constexpr int TH = 4 * WM, NT = WM * 128;
@@ -692,7 +847,8 @@ static hipError_t launch_t(const ConvArgs& a, hipStream_t s) {
 static const char* const kVariantNames[CONV_NUM_VARIANTS] = {
     "conv_igemm_kernel<2,2,4> generic 128x128", "conv_igemm_kernel<4,1,2> generic 128x64",
     "conv3x3_halo_kernel<2,2> 3x3 s1 8x16px x128ch", "conv3x3_pp_kernel<2> 3x3 s1 16x16px x64ch",
-    "conv3x3_pp_kernel<4> 3x3 s1 16x16px x128ch", "conv3x3_halo_kernel<4,*> 3x3 s1 16x16px x128ch"};
+    "conv3x3_pp_kernel<4> 3x3 s1 16x16px x128ch", "conv3x3_halo_kernel<4,*> 3x3 s1 16x16px x128ch",
+    "conv3x3_c64_kernel 3x3 s1 64->64 persistent"};
 const char* conv_variant_name(int v) { return v >= 0 && v < CONV_NUM_VARIANTS ? kVariantNames[v] : "?"; }
 
 int conv_variant(Precision p, const ConvArgs& a) {
@@ -703,6 +859,7 @@ int conv_variant(Precision p, const ConvArgs& a) {
     if (p == PREC_F16 && a.k == 3 && a.s == 1 && a.c1 == 0 && !a.up0 && !a.out_f32 && a.Cin % 64 == 0 &&
         a.out_bs == a.Ho * a.Wo && a.out_ro == 0) {
         static const int force = getenv("CY_HALO_WM") ? atoi(getenv("CY_HALO_WM")) : 0;     // tuning override
+        if (narrow && a.Cin == 64 && force != 8) return force == 9 ? CONV_GENERIC_64 : CONV_C64_PERSIST;
         if (narrow) return force == 9 ? CONV_GENERIC_64 : CONV_PP_64;
         if (force == 5) return CONV_PP_128;
         if (force == 4 || force == 43) return CONV_HALO16_128;
@@ -713,6 +870,7 @@ int conv_variant(Precision p, const ConvArgs& a) {
 
 hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s) {
     switch (conv_variant(p, a)) {
+        case CONV_C64_PERSIST: return launch_c64(a, s);
         case CONV_PP_64: return launch_pp<2>(a, s);
         case CONV_PP_128: { ConvArgs b2 = a; b2.dbg = getenv("CY_DBG") ? atoi(getenv("CY_DBG")) : 0; return launch_pp<4>(b2, s); }
         case CONV_HALO16_128: return (getenv("CY_HALO_WM") && atoi(getenv("CY_HALO_WM")) == 43) ? launch_halo<4, 3>(a, s) : launch_halo<4, 2>(a, s);

@@ -5,6 +5,7 @@
 #include "cy_plan.h"
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -317,50 +318,87 @@ int cy_forward(cy_ctx* c, const void* d_netin, int B, int H, int W, float* d_pre
         c->prof.push_back({ev_prev, e, kind, flops, cur_conv});
         ev_prev = e;
     };
-    for (const Op& o : p.ops) {
+    // Optional (CY_SUB=n): run the full-resolution head of the graph (stem .. model.2, levels 1-2; tensors of 134-537 MB
+    // at batch 64) in sub-batches so that producer and consumer could meet in the 256 MiB Infinity Cache; only the
+    // stage output and the network input are addressed per sub-batch.  Measured on MI355X: 1-6 % SLOWER at n = 4/8/16
+    // (the extra launches cost more than the cache buys), so it is off by default and kept as a tuning knob.
+    static const int sub_env = getenv("CY_SUB") ? atoi(getenv("CY_SUB")) : 0;   // measured: no gain on MI355X (profiles/), off by default
+    size_t n_head = 0;
+    while (n_head < p.ops.size()) {
+        const Op& o = p.ops[n_head];
+        const int lo = o.out >= 0 ? p.tensors[o.out].level : 9;
+        if (lo > 2 || o.in1 >= 0) break;
+        ++n_head;
+    }
+    std::vector<char> crosses(p.tensors.size(), 0);      // written in the head, read after it
+    for (size_t i = n_head; i < p.ops.size(); ++i) {
+        const Op& o = p.ops[i];
+        if (o.in0 >= 0) crosses[o.in0] = 1;
+        if (o.in1 >= 0) crosses[o.in1] = 1;
+        if (o.res >= 0) crosses[o.res] = 1;
+    }
+    crosses[0] = 1;
+    const int sub = (sub_env > 0 && sub_env < B && n_head > 0) ? sub_env : B;
+
+    auto run_op = [&](const Op& o, int b0, int Bn) -> int {
+        auto tp = [&](int t) -> char* {                    // tensor base for images [b0, b0+Bn)
+            char* base = tptr(t);
+            if (b0 && crosses[t]) base += (size_t)b0 * (H >> p.tensors[t].level) * (W >> p.tensors[t].level) * p.tensors[t].C * es;
+            return base;
+        };
         cur_conv = o.conv;
         if (o.kind == OPK_STEM) {
             const Tensor& ti = p.tensors[o.in0]; const Tensor& to = p.tensors[o.out];
             StemArgs a{};
-            a.in = tptr(o.in0); a.out = tptr(o.out); a.w = c->dconv[o.conv].stem_w; a.bias = c->dconv[o.conv].bias; a.wpk = c->dconv[o.conv].w;
-            a.B = B; a.Hi = H >> ti.level; a.Wi = W >> ti.level; a.Ho = H >> to.level; a.Wo = W >> to.level;
+            a.in = tp(o.in0); a.out = tp(o.out); a.w = c->dconv[o.conv].stem_w; a.bias = c->dconv[o.conv].bias; a.wpk = c->dconv[o.conv].w;
+            a.B = Bn; a.Hi = H >> ti.level; a.Wi = W >> ti.level; a.Ho = H >> to.level; a.Wo = W >> to.level;
             a.Cout = p.convs[o.conv].cout; a.out_ct = to.C; a.out_coff = o.out_coff;
             HIPCHK(c, launch_stem(c->prec, a, s));
-            prof_done(CONV_NUM_VARIANTS, 2.0 * B * a.Ho * a.Wo * a.Cout * 27.0);
+            prof_done(CONV_NUM_VARIANTS, 2.0 * Bn * a.Ho * a.Wo * a.Cout * 27.0);
         } else if (o.kind == OPK_POOL) {
             const Tensor& t = p.tensors[o.in0];
             PoolArgs a{};
-            a.src = tptr(o.in0); a.dst = tptr(o.out); a.ct = t.C; a.src_coff = o.in0_coff; a.dst_coff = o.out_coff;
-            a.C = o.c0; a.B = B; a.H = H >> t.level; a.W = W >> t.level;
+            a.src = tp(o.in0); a.dst = tp(o.out); a.ct = t.C; a.src_coff = o.in0_coff; a.dst_coff = o.out_coff;
+            a.C = o.c0; a.B = Bn; a.H = H >> t.level; a.W = W >> t.level;
             HIPCHK(c, launch_pool5(c->prec, a, s));
             prof_done(CONV_NUM_VARIANTS + 1, 0.0);
         } else {
             const ConvDesc& d = p.convs[o.conv];
             ConvArgs a{};
             const Tensor& t0 = p.tensors[o.in0];
-            a.in0 = tptr(o.in0); a.in0_ct = t0.C; a.in0_coff = o.in0_coff; a.c0 = o.c0; a.up0 = o.up0;
-            a.in0_bytes = (uint32_t)(o.in0 == 0 ? (size_t)B * H * W * 4 * es : c->tbytes[o.in0]);
+            auto span = [&](int t) -> uint32_t {           // bytes addressable from tp(t) for Bn images
+                const Tensor& tt = p.tensors[t];
+                return (uint32_t)((size_t)Bn * (H >> tt.level) * (W >> tt.level) * tt.C * es);
+            };
+            a.in0 = tp(o.in0); a.in0_ct = t0.C; a.in0_coff = o.in0_coff; a.c0 = o.c0; a.up0 = o.up0;
+            a.in0_bytes = span(o.in0);
             int lev_in = o.up0 ? t0.level - 1 : t0.level;
             if (o.in1 >= 0) {
                 const Tensor& t1 = p.tensors[o.in1];
-                a.in1 = tptr(o.in1); a.in1_ct = t1.C; a.in1_coff = o.in1_coff; a.c1 = o.c1; a.in1_bytes = (uint32_t)c->tbytes[o.in1];
+                a.in1 = tp(o.in1); a.in1_ct = t1.C; a.in1_coff = o.in1_coff; a.c1 = o.c1; a.in1_bytes = span(o.in1);
                 lev_in = t1.level;
             }
             a.wgt = c->dconv[o.conv].w; a.wgt_bytes = (uint32_t)c->dconv[o.conv].wbytes; a.bias = c->dconv[o.conv].bias;
-            a.B = B; a.Hi = H >> lev_in; a.Wi = W >> lev_in; a.k = d.k; a.s = d.s; a.act = d.act;
+            a.B = Bn; a.Hi = H >> lev_in; a.Wi = W >> lev_in; a.k = d.k; a.s = d.s; a.act = d.act;
             a.Ho = d.s == 2 ? a.Hi / 2 : a.Hi; a.Wo = d.s == 2 ? a.Wi / 2 : a.Wi;
             a.Cin = d.cin; a.Cout = d.cout;
             if (o.out >= 0) {
                 const Tensor& to = p.tensors[o.out];
-                a.out = tptr(o.out); a.out_ct = to.C; a.out_coff = o.out_coff; a.out_bs = a.Ho * a.Wo; a.out_ro = 0; a.out_f32 = 0;
+                a.out = tp(o.out); a.out_ct = to.C; a.out_coff = o.out_coff; a.out_bs = a.Ho * a.Wo; a.out_ro = 0; a.out_f32 = 0;
             } else {
                 a.out = d_pred; a.out_ct = 64 + p.nc; a.out_coff = o.pred_coff; a.out_bs = A; a.out_ro = a_off[o.pred_level]; a.out_f32 = 1;
             }
-            if (o.res >= 0) { a.res = tptr(o.res); a.res_ct = p.tensors[o.res].C; a.res_coff = o.res_coff; }
+            if (o.res >= 0) { a.res = tp(o.res); a.res_ct = p.tensors[o.res].C; a.res_coff = o.res_coff; }
             HIPCHK(c, launch_conv(c->prec, a, s));
-            prof_done(conv_variant(c->prec, a), 2.0 * B * a.Ho * a.Wo * (double)a.Cout * a.Cin * a.k * a.k);
+            prof_done(conv_variant(c->prec, a), 2.0 * Bn * a.Ho * a.Wo * (double)a.Cout * a.Cin * a.k * a.k);
         }
+        return CY_OK;
+    };
+    for (int b0 = 0; b0 < B; b0 += sub) {
+        const int Bn = B - b0 < sub ? B - b0 : sub;
+        for (size_t i = 0; i < n_head; ++i) { rc = run_op(p.ops[i], b0, Bn); if (rc) return rc; }
     }
+    for (size_t i = n_head; i < p.ops.size(); ++i) { rc = run_op(p.ops[i], 0, B); if (rc) return rc; }
     return CY_OK;
 }
 
