@@ -82,10 +82,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         log("note: WORLD_SIZE=%d, --gpus=%d; using WORLD_SIZE" % (world, args.gpus))
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("CY_BENCH_BACKEND", "nccl")     # "gloo": rehearsal of the N>1 path on fewer GPUs than ranks
+    if local >= ndev and backend == "nccl":
+        raise SystemExit("rank %d has no GPU (found %d); one process per GPU is required" % (rank, ndev))
+    local = local % max(ndev, 1)
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     if rank == 0:
         ge.build()
     if world > 1:
@@ -117,7 +125,7 @@ def main():
         eng.gather()
         src = stats = None
         if rank == 0:
-            src, stats = eng.catalog(model.names)     # .cpu() inside synchronises the stream
+            src, stats = eng.merged_records()         # final catalog records in host memory (D2H synchronises)
         else:
             torch.cuda.synchronize()
         return src, stats
@@ -137,7 +145,7 @@ def main():
         dist.barrier()
     dt = time.time() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     prof = det.profile_summary() if not args.no_profile else None

@@ -38,6 +38,36 @@ def shard(items, rank, world):
     return items[lo:hi]
 
 
+def partition_tiles(grid, imgsz, world):
+    """Deterministic cost-balanced tile -> rank assignment (every rank computes the same one).
+
+    Tiles are grouped by shape (one kernel-launch sequence per shape), shapes ordered by letterboxed area (largest
+    first), the concatenated list is cut into `world` contiguous runs of equal cost (cost = letterboxed pixels).  A rank
+    therefore sees at most a couple of shape classes and few, large batches -- with plain per-class round-robin every
+    rank would get a sliver of each ragged class and pay a ~100-launch sequence for a handful of tiles.
+    Returns per rank: list of ((th, tw), [tile ids])."""
+    classes = {}
+    for tid, (x0, x1, y0, y1) in enumerate(grid):
+        classes.setdefault((y1 - y0, x1 - x0), []).append(tid)
+    cost = {}
+    for (th, tw) in classes:
+        lb = L.letterbox(th, tw, imgsz)
+        cost[(th, tw)] = lb.H * lb.W
+    order = sorted(classes, key=lambda k: (-cost[k], -k[0], -k[1]))
+    seq = [(shp, t) for shp in order for t in classes[shp]]
+    total = float(sum(cost[shp] for shp, _ in seq))
+    out = [[] for _ in range(world)]
+    acc, r = 0.0, 0
+    for shp, t in seq:
+        while r < world - 1 and acc >= total * (r + 1) / world:          # half-open runs: [total*r/world, total*(r+1)/world)
+            r += 1
+        if not out[r] or out[r][-1][0] != shp:
+            out[r].append((shp, []))
+        out[r][-1][1].append(t)
+        acc += cost[shp]
+    return out
+
+
 class TileEngine(object):
     """Runs the per-tile path for this rank's share of a tile grid and merges all ranks' detections."""
 
@@ -46,14 +76,23 @@ class TileEngine(object):
         self.pre_cfg, self.imgsz = pre_cfg, int(imgsz)
         self.conf, self.iou, self.soft, self.hard = float(conf), float(iou), float(soft), float(hard)
         self.rank, self.world, self.batch = rank, world, min(int(batch), detector.max_batch)
-        # shape classes in order of first appearance; every rank derives the same assignment
-        classes = {}
-        for tid, (x0, x1, y0, y1) in enumerate(self.grid):
-            classes.setdefault((y1 - y0, x1 - x0), []).append(tid)
-        self.classes = classes
-        self.my = {shp: shard(tids, rank, world) for shp, tids in classes.items()}
-        self.cap_tiles = max(sum(len(shard(t, r, world)) for t in classes.values()) for r in range(world))
-        n_my = sum(len(v) for v in self.my.values())
+        parts = partition_tiles(self.grid, self.imgsz, world)
+        self.counts = [sum(len(t) for _, t in p) for p in parts]
+        self.cap_tiles = max(max(self.counts), 1)
+        self.my = parts[rank]
+        n_my = self.counts[rank]
+        # launch plan, built once: (th, tw, B, ctypes origins, first row)
+        self.plan, row = [], 0
+        for (th, tw), tids in self.my:
+            nb = (len(tids) + self.batch - 1) // self.batch        # equal-sized batches (198 tiles -> 50,50,49,49, not 64,64,64,6)
+            i = 0
+            for k in range(nb):
+                n = len(tids) // nb + (1 if k < len(tids) % nb else 0)
+                chunk = tids[i:i + n]
+                i += n
+                xy = [(self.grid[t][0], self.grid[t][2]) for t in chunk]
+                self.plan.append((th, tw, len(chunk), xy, row))
+                row += len(chunk)
         dev = detector.tdev
         # fixed-capacity record buffer: [tile][300*6 floats | count | status | tile id]
         self.rec = torch.zeros((self.cap_tiles, L.CY_MAX_DET * 6 + 3), dtype=torch.float32, device=dev)
@@ -61,82 +100,78 @@ class TileEngine(object):
         self.det_all = torch.zeros((max(n_my, 1), L.CY_MAX_DET, 6), dtype=torch.float32, device=dev)
         self.cnt_all = torch.zeros((max(n_my, 1),), dtype=torch.int32, device=dev)
         self.st_all = torch.zeros((max(n_my, 1),), dtype=torch.int32, device=dev)
-        order = [t for tids in self.my.values() for t in tids]
+        order = [t for _, tids in self.my for t in tids]
         self.tid_all = torch.tensor(order if order else [0], dtype=torch.float32, device=dev)
         self.n_my = n_my
         self.gathered = None
 
     def run_local(self):
         """Enqueue every batch of this rank's tiles (software-pipelined inside the library); results stay on device."""
-        row = 0
-        for (th, tw), tids in self.my.items():
-            for i in range(0, len(tids), self.batch):
-                chunk = tids[i:i + self.batch]
-                B = len(chunk)
-                xy = [(self.grid[t][0], self.grid[t][2]) for t in chunk]
-                out = (self.det_all[row:row + B], self.cnt_all[row:row + B], self.st_all[row:row + B])
-                self.det.detect_tiles(self.mosaic, xy, th, tw, self.imgsz, self.pre_cfg, self.conf, self.iou,
-                                      self.soft, self.hard, out=out, flush=False)
-                row += B
+        for th, tw, B, xy, row in self.plan:
+            out = (self.det_all[row:row + B], self.cnt_all[row:row + B], self.st_all[row:row + B])
+            self.det.detect_tiles(self.mosaic, xy, th, tw, self.imgsz, self.pre_cfg, self.conf, self.iou,
+                                  self.soft, self.hard, out=out, flush=False)
         if hasattr(self.det, "flush"):
             self.det.flush()
         n = self.n_my
-        self.rec.zero_()
         if n:
             self.rec[:n, :L.CY_MAX_DET * 6] = self.det_all[:n].reshape(n, -1)
             self.rec[:n, -3] = self.cnt_all[:n].float()
             self.rec[:n, -2] = self.st_all[:n].float()
             self.rec[:n, -1] = self.tid_all[:n]
-        return row
+        return n
 
     def gather(self):
         """ONE collective: all-gather of the fixed-capacity record buffers (RCCL over xGMI when world > 1)."""
         if self.world > 1:
             import torch.distributed as dist
             out = torch.empty((self.world,) + tuple(self.rec.shape), dtype=self.rec.dtype, device=self.rec.device)
-            if dist.get_backend() == "gloo":          # CPU rehearsal of the same collective (tests)
-                parts = [torch.empty_like(self.rec) for _ in range(self.world)]
-                dist.all_gather(parts, self.rec)
-                out = torch.stack(parts, 0)
+            if dist.get_backend() == "gloo":          # CPU rehearsal of the same collective (tests, 1-GPU boxes)
+                mine = self.rec.cpu()
+                parts = [torch.empty_like(mine) for _ in range(self.world)]
+                dist.all_gather(parts, mine)
+                out = torch.stack(parts, 0).to(self.rec.device)
             else:
                 dist.all_gather_into_tensor(out, self.rec)
-            self.gathered = out.reshape(-1, self.rec.shape[1])
-            self._valid = []
-            for r in range(self.world):
-                n = sum(len(shard(t, r, self.world)) for t in self.classes.values())
-                self._valid.append((r * self.cap_tiles, n))
+            self.gathered = out
         else:
-            self.gathered = self.rec
-            self._valid = [(0, self.n_my)]
+            self.gathered = self.rec.unsqueeze(0)
         return self.gathered
 
+    def merged_records(self):
+        """All ranks' records -> tile-id order -> edge flags + cross-tile merge.  Returns (records [M,8] float64 =
+        x1,y1,x2,y2,score,class_id,edge,merged in catalog order, stats).  Valid rows are compacted on device first, so
+        only the detections themselves cross PCIe."""
+        g = self.gathered
+        valid = torch.zeros(g.shape[:2], dtype=torch.bool, device=g.device)
+        for r, n in enumerate(self.counts):
+            valid[r, :n] = True
+        rows = g[valid]                                            # [T, 1803]
+        tid = rows[:, -1].long()
+        rows = rows[torch.argsort(tid, stable=True)]
+        cnt, status, tid = rows[:, -3].long(), rows[:, -2].long(), rows[:, -1].long()
+        cnt = torch.where(status == 0, cnt, torch.zeros_like(cnt))
+        keep = torch.arange(L.CY_MAX_DET, device=g.device)[None, :] < cnt[:, None]
+        det = rows[:, :L.CY_MAX_DET * 6].reshape(-1, L.CY_MAX_DET, 6)[keep]          # [Ndet, 6] in tile-id order
+        dtile = torch.repeat_interleave(tid, cnt)
+        stats = {"tiles": int(rows.shape[0]), "skipped": int((status != 0).sum()), "per_tile_detections": int(cnt.sum())}
+        det_h = np.ascontiguousarray(det.cpu().numpy(), np.float32)
+        dtile_h = np.ascontiguousarray(dtile.cpu().numpy().astype(np.int32))
+        return merge_records(det_h, dtile_h, self.grid), stats
+
     def catalog(self, names):
-        """Records of all ranks -> tile-id order -> edge flags + cross-tile merge -> the reference's source dicts."""
-        g = self.gathered.cpu().numpy()
-        rows = np.concatenate([g[o:o + n] for o, n in self._valid], 0) if self._valid else g[:0]
-        return build_catalog(rows, self.grid, names)
+        """-> (the reference's list of source dicts, stats)."""
+        rec, stats = self.merged_records()
+        return records_to_sources(rec, names), stats
 
 
-def build_catalog(rows, grid, names):
-    """rows: [ntiles, 300*6+3] host records (any order).  Returns (sources list, per-tile stats dict)."""
-    tid = rows[:, -1].astype(np.int64)
-    order = np.argsort(tid, kind="stable")
-    rows = rows[order]
-    cnt = rows[:, -3].astype(np.int64)
-    status = rows[:, -2].astype(np.int64)
-    dets, dtile = [], []
-    for r in range(rows.shape[0]):
-        if status[r] != 0 or cnt[r] == 0:
-            continue
-        dets.append(rows[r, :cnt[r] * 6].reshape(-1, 6))
-        dtile.append(np.full(cnt[r], rows[r, -1], np.int32))
-    stats = {"tiles": int(rows.shape[0]), "skipped": int(np.sum(status != 0)), "per_tile_detections": int(cnt[status == 0].sum())}
-    if not dets:
-        return [], stats
-    det = np.ascontiguousarray(np.concatenate(dets, 0), np.float32)
-    dtile = np.ascontiguousarray(np.concatenate(dtile, 0), np.int32)
+def merge_records(det, dtile, grid):
+    """det [n,6] float32 tile-pixel detections grouped by ascending tile id, dtile [n] int32 -> merged records [M,8]."""
+    n = det.shape[0]
+    if n == 0:
+        return np.zeros((0, 8), np.float64)
     tiles = np.ascontiguousarray(np.array(grid, np.int32).reshape(-1, 4))
-    n, T = det.shape[0], tiles.shape[0]
+    T = tiles.shape[0]
     lib = L.load()
     ip, fp, dp = C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_double)
     rec = np.zeros((n, 8), np.float64)
@@ -144,7 +179,21 @@ def build_catalog(rows, grid, names):
                                      rec.ctypes.data_as(dp)))
     out = np.zeros((n, 8), np.float64)
     m = L.check(lib.cy_merge_edge_sources(rec.ctypes.data_as(dp), n, tiles.ctypes.data_as(ip), T, out.ctypes.data_as(dp)))
-    return records_to_sources(out[:m], names), stats
+    return out[:m]
+
+
+def build_catalog(rows, grid, names):
+    """rows: [ntiles, 300*6+3] host records (any order).  Returns (sources list, per-tile stats dict)."""
+    tid = rows[:, -1].astype(np.int64)
+    rows = rows[np.argsort(tid, kind="stable")]
+    cnt = rows[:, -3].astype(np.int64)
+    status = rows[:, -2].astype(np.int64)
+    cnt = np.where(status == 0, cnt, 0)
+    stats = {"tiles": int(rows.shape[0]), "skipped": int(np.sum(status != 0)), "per_tile_detections": int(cnt.sum())}
+    keep = np.arange(L.CY_MAX_DET)[None, :] < cnt[:, None]
+    det = np.ascontiguousarray(rows[:, :L.CY_MAX_DET * 6].reshape(-1, L.CY_MAX_DET, 6)[keep], np.float32)
+    dtile = np.ascontiguousarray(np.repeat(rows[:, -1].astype(np.int32), cnt))
+    return records_to_sources(merge_records(det, dtile, grid), names), stats
 
 
 _EDGE = {0.0: 0, 1.0: 1, 2.0: True}        # the reference mixes int and bool in this field (SURVEY Appendix C Q7)
