@@ -68,7 +68,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=16384, help="mosaic edge (default: the 16k config)")
-    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--batch", type=int, default=192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-launch hipEvents in the timed region")
     args = ap.parse_args()
@@ -120,18 +120,27 @@ def main():
     if rank == 0:
         log("setup %.1f s: %d tiles, %d ranks, %d tiles on rank 0" % (time.time() - t_setup, len(grid), world, eng.n_my))
 
+    tsplit = {"local": 0.0, "gather": 0.0, "merge": 0.0}
+
     def step():
+        t0 = time.time()
         eng.run_local()
+        torch.cuda.synchronize()
+        t1 = time.time()
         eng.gather()
+        torch.cuda.synchronize()
+        t2 = time.time()
         src = stats = None
         if rank == 0:
             src, stats = eng.merged_records()         # final catalog records in host memory (D2H synchronises)
-        else:
-            torch.cuda.synchronize()
+        t3 = time.time()
+        tsplit["local"] += t1 - t0; tsplit["gather"] += t2 - t1; tsplit["merge"] += t3 - t2
         return src, stats
 
     for _ in range(args.warmup):
         step()
+    for k in tsplit:
+        tsplit[k] = 0.0
     if not args.no_profile:
         det.profile(True)
     if world > 1:
@@ -165,6 +174,7 @@ def main():
                        "sources_in_catalog": len(src), "tiles_skipped": stats["skipped"],
                        "per_tile_detections": stats["per_tile_detections"]},
             "conv_stack_mfma_frac_whole_job": value * FLOP_PER_TILE_512 / 1e12 / (PEAK_FP16_DENSE_TFLOPS * world),
+            "step_split_ms_rank0": {k: 1000.0 * v / args.steps for k, v in tsplit.items()},
         }
         if prof:
             prof = [p for p in prof if p["launches"]]

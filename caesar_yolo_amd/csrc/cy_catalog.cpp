@@ -18,13 +18,47 @@ inline bool tiles_neighbors(const int* a, const int* b) {
     const bool ovl = !(ax1 < bx0 || ax0 > bx1 || ay1 < by0 || ay0 > by1);
     return (adjx && adjy) || ovl;
 }
-// neighbour tile ids per tile (ascending), only for tiles flagged in `need`
+// neighbour tile ids per tile (ascending), only for tiles flagged in `need`.
+// The pair test factorises per axis -- neighbour = (adjX && adjY) || (ovlX && ovlY) -- so it is evaluated between the
+// DISTINCT x-ranges and y-ranges of the grid (tens, not thousands) and expanded through a (x-range, y-range) -> tiles
+// table: O(T * neighbours) instead of the reference's O(T^2) pair loop (inference.py:1034-1071), same lists.
 std::vector<std::vector<int>> neighbor_lists(const int* tiles, int T, const std::vector<char>& need) {
     std::vector<std::vector<int>> nb(T);
+    std::vector<std::pair<int, int>> xs, ys;
+    std::vector<int> xi(T), yi(T);
+    auto index_of = [](std::vector<std::pair<int, int>>& v, std::pair<int, int> r) {
+        for (size_t k = 0; k < v.size(); ++k) if (v[k] == r) return (int)k;
+        v.push_back(r);
+        return (int)v.size() - 1;
+    };
+    for (int i = 0; i < T; ++i) {
+        xi[i] = index_of(xs, {tiles[4 * i], tiles[4 * i + 1]});
+        yi[i] = index_of(ys, {tiles[4 * i + 2], tiles[4 * i + 3]});
+    }
+    const int NX = (int)xs.size(), NY = (int)ys.size();
+    if ((long)NX * NY > 4L * T + 64) {                       // irregular tile set: plain pair loop
+        for (int i = 0; i < T; ++i) {
+            if (!need[i]) continue;
+            for (int j = 0; j < T; ++j)
+                if (j != i && tiles_neighbors(tiles + 4 * i, tiles + 4 * j)) nb[i].push_back(j);
+        }
+        return nb;
+    }
+    auto adj = [](std::pair<int, int> a, std::pair<int, int> b) { return a.second == b.first - 1 || a.first == b.second + 1 || a == b; };
+    auto ovl = [](std::pair<int, int> a, std::pair<int, int> b) { return !(a.second < b.first || a.first > b.second); };
+    std::vector<std::vector<int>> cell((size_t)NX * NY);
+    for (int i = 0; i < T; ++i) cell[(size_t)xi[i] * NY + yi[i]].push_back(i);
+    std::vector<std::vector<std::pair<int, int>>> relx(NX), rely(NY);   // (other index, bit0 = adjacent | bit1 = overlapping)
+    for (int a = 0; a < NX; ++a) for (int b = 0; b < NX; ++b) { const int f = (adj(xs[a], xs[b]) ? 1 : 0) | (ovl(xs[a], xs[b]) ? 2 : 0); if (f) relx[a].push_back({b, f}); }
+    for (int a = 0; a < NY; ++a) for (int b = 0; b < NY; ++b) { const int f = (adj(ys[a], ys[b]) ? 1 : 0) | (ovl(ys[a], ys[b]) ? 2 : 0); if (f) rely[a].push_back({b, f}); }
     for (int i = 0; i < T; ++i) {
         if (!need[i]) continue;
-        for (int j = 0; j < T; ++j)
-            if (j != i && tiles_neighbors(tiles + 4 * i, tiles + 4 * j)) nb[i].push_back(j);
+        for (auto& rx : relx[xi[i]])
+            for (auto& ry : rely[yi[i]]) {
+                if (!((rx.second & ry.second & 1) || (rx.second & ry.second & 2))) continue;
+                for (int j : cell[(size_t)rx.first * NY + ry.first]) if (j != i) nb[i].push_back(j);
+            }
+        std::sort(nb[i].begin(), nb[i].end());
     }
     return nb;
 }
@@ -73,27 +107,39 @@ extern "C" int cy_merge_edge_sources(const double* rec, int n, const int* tiles,
     }
     const int N = (int)tbm.size();
     if (N == 0) return nout;
-    // sources of each tile (positions in tbm are ascending because records are grouped by ascending tile)
-    std::vector<std::vector<int>> by_tile(T);
+    // sources of each tile (positions in tbm are ascending because records are grouped by ascending tile): CSR
+    std::vector<int> tstart(T + 1, 0);
     std::vector<char> need(T, 0);
-    for (int k = 0; k < N; ++k) { const int t = (int)rec[8 * tbm[k] + 6]; if (t < 0 || t >= T) return CY_ERR_ARG; by_tile[t].push_back(k); need[t] = 1; }
+    for (int k = 0; k < N; ++k) { const int t = (int)rec[8 * tbm[k] + 6]; if (t < 0 || t >= T) return CY_ERR_ARG; tstart[t + 1]++; need[t] = 1; }
+    for (int t = 0; t < T; ++t) tstart[t + 1] += tstart[t];
+    for (int k = 1; k < N; ++k) if (rec[8 * tbm[k] + 6] < rec[8 * tbm[k - 1] + 6]) return CY_ERR_ARG;   // must be tile-ordered
     const auto nb = neighbor_lists(tiles, T, need);
-    std::vector<std::vector<int>> adj(N);
+    // overlapping pairs (i < j) between sources of neighbouring tiles, generated in lexicographic order, so the CSR rows
+    // below come out ascending == the reference's adjacency insertion order (i asc, then j asc)
+    std::vector<std::pair<int, int>> pairs;
+    std::vector<int> deg(N + 1, 0);
+    std::vector<double> box(4 * (size_t)N);       // compact copy of the edge sources' boxes (cache-friendly pair loop)
+    std::vector<int> tof(N);
+    for (int k = 0; k < N; ++k) { const double* r = rec + 8 * tbm[k]; box[4 * k] = r[0]; box[4 * k + 1] = r[1]; box[4 * k + 2] = r[2]; box[4 * k + 3] = r[3]; tof[k] = (int)r[6]; }
+    pairs.reserve(N);
     for (int i = 0; i < N; ++i) {
-        const double* a = rec + 8 * tbm[i];
-        const int ti = (int)a[6];
+        const double ax1 = box[4 * i], ay1 = box[4 * i + 1], ax2 = box[4 * i + 2], ay2 = box[4 * i + 3];
+        const int ti = tof[i];
         for (int tj : nb[ti]) {                   // tid_j in neighborTileIds(tile_i): a tile is never its own neighbour
-            for (int j : by_tile[tj]) {
+            if (tj < ti) continue;                // j > i implies tile_j >= tile_i
+            for (int j = tstart[tj]; j < tstart[tj + 1]; ++j) {
                 if (j <= i) continue;
-                const double* b = rec + 8 * tbm[j];
-                if (a[2] < b[0] || a[0] > b[2] || a[3] < b[1] || a[1] > b[3]) continue;
-                adj[i].push_back(j); adj[j].push_back(i);
+                const double* b = &box[4 * j];
+                if (ax2 < b[0] || ax1 > b[2] || ay2 < b[1] || ay1 > b[3]) continue;
+                pairs.push_back({i, j}); deg[i + 1]++; deg[j + 1]++;
             }
         }
     }
-    for (auto& v : adj) std::sort(v.begin(), v.end());     // == the reference's insertion order (i asc, then j asc)
+    for (int v = 0; v < N; ++v) deg[v + 1] += deg[v];
+    std::vector<int> adjv(pairs.size() * 2), fill(deg.begin(), deg.end() - 1);
+    for (auto& pr : pairs) { adjv[fill[pr.first]++] = pr.second; adjv[fill[pr.second]++] = pr.first; }
     std::vector<char> vis(N, 0);
-    std::vector<int> comp, stk, cur(N, 0);
+    std::vector<int> comp, stk, cur(deg.begin(), deg.end() - 1);
     for (int v0 = 0; v0 < N; ++v0) {
         if (vis[v0]) continue;
         comp.clear(); stk.clear();
@@ -101,8 +147,8 @@ extern "C" int cy_merge_edge_sources(const double* rec, int n, const int* tiles,
         while (!stk.empty()) {                    // iterative form of the recursive DFS preorder
             const int v = stk.back();
             bool pushed = false;
-            while (cur[v] < (int)adj[v].size()) {
-                const int u = adj[v][cur[v]++];
+            while (cur[v] < deg[v + 1]) {
+                const int u = adjv[cur[v]++];
                 if (!vis[u]) { vis[u] = 1; comp.push_back(u); stk.push_back(u); pushed = true; break; }
             }
             if (!pushed) stk.pop_back();

@@ -92,11 +92,11 @@ hipError_t launch_iou_merge(const MergeArgs& a, hipStream_t s);
 enum PreOp { OP_BKG = 1, OP_SHIFT = 2, OP_CLIP = 3, OP_ZSCALE = 4, OP_HISTEQ = 5, OP_MINMAX = 6 };
 struct PreStage { int op; double p0, p1, p2; int flag; };   // op parameters (see cy_preproc.hip)
 constexpr int MAX_STAGES = 8;
-constexpr int MAX_PRE_BATCH = 128;
+constexpr int MAX_PRE_BATCH = 256;
 struct PreProgram { int n; PreStage st[MAX_STAGES]; };
 struct PreArgs {
     const float* mosaic; int MH, MW;      // resident mosaic, native-endian fp32, non-finite already 0
-    int txy[2 * 128];                      // tile origins x0,y0 in mosaic pixels, B <= 128 (kernel argument: no staging copy)
+    int txy[2 * 256];                      // tile origins x0,y0 in mosaic pixels, B <= 256 (kernel argument: no staging copy)
     int B, th, tw;                         // tile box of this shape class
     PreProgram prog[3]; int nprog;         // 1: one program broadcast to 3 channels; 3: per-channel programs
     double* params;                        // [B][3][MAX_STAGES][4] solved stage parameters (workspace / witness)

@@ -524,7 +524,7 @@ int cy_preproc(cy_ctx* c, const float* d_mosaic, int MH, int MW, const int* h_ti
     cy_letterbox lb;
     if (cy_letterbox_geometry(th, tw, imgsz, &lb)) return fail(c, CY_ERR_ARG, "bad tile/imgsz");
     if (lb.H > c->cfg.max_h || lb.W > c->cfg.max_w) return fail(c, CY_ERR_ARG, "letterboxed tile exceeds max_h/max_w of the context");
-    if (B > MAX_PRE_BATCH) return fail(c, CY_ERR_ARG, "at most 128 tiles per cy_preproc call");
+    if (B > MAX_PRE_BATCH) return fail(c, CY_ERR_ARG, "at most 256 tiles per cy_preproc call");
     PreArgs a{};
     for (int b = 0; b < B; ++b) {
         a.txy[2 * b] = h_tiles[2 * b]; a.txy[2 * b + 1] = h_tiles[2 * b + 1];
