@@ -172,6 +172,7 @@ def main():
                                    "merge 0.3/0.8, per-tile IoU merge + cross-tile merge" % (args.size, args.size, ntiles),
                        "tiles": ntiles, "tile_batch": args.batch, "parallelism": "tile-sharded x%d" % world,
                        "sources_in_catalog": len(src), "tiles_skipped": stats["skipped"],
+                       "merge_host_ms": stats.get("merge_host_ms"), "merge_d2h_ms": stats.get("merge_d2h_ms"),
                        "per_tile_detections": stats["per_tile_detections"]},
             "conv_stack_mfma_frac_whole_job": value * FLOP_PER_TILE_512 / 1e12 / (PEAK_FP16_DENSE_TFLOPS * world),
             "step_split_ms_rank0": {k: 1000.0 * v / args.steps for k, v in tsplit.items()},

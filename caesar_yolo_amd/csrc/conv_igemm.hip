@@ -15,7 +15,8 @@
 // 16-byte pieces global -> LDS directly (`buffer_load_dwordx4 ... lds`, no VGPR staging, no ds_write); the buffer
 // range check supplies the zero padding of the 3x3 halo and of ragged channel counts (an out-of-range offset
 // writes 0).  The LDS image is double-buffered and XOR-swizzled through the SOURCE address so that ds_read_b128
-// fragment reads are conflict-free (slot = chunk ^ ((row>>1)&7); a 256-byte bank row holds two 128-byte tile rows).
+// fragment reads are conflict-free (slot = chunk ^ (row & 7): conflict-free for any 16 consecutive rows, whatever the first row -- the 3x3 taps of the
+// halo kernels read at arbitrary row offsets; a 256-byte bank row holds two 128-byte tile rows).
 #include "cy_kernels.h"
 #include <cstdlib>
 
@@ -29,6 +30,14 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 #define CY_OOB 0xFFFFFF00u
+
+// developer diagnostics (CY_DBG bit 6): per-segment s_memtime sums of the halo kernel's tap loop, summed over waves
+__device__ unsigned long long g_stamps[8];
+__device__ __forceinline__ unsigned long long stamp_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
 
 __device__ __forceinline__ float silu_exact(float x) { return x / (1.0f + expf(-x)); }
 // fp16 context: x * sigmoid(x) with the hardware exp2/rcp (1 ulp each; the result is rounded to fp16 anyway):
@@ -103,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     // so the XOR swizzle moves to the SOURCE: the lane that owns slot s of row r fetches logical chunk s ^ ((r>>1)&7)
     // (the same involution the fragment reads apply).  ((r>>1)&7 does not depend on i because 32*i>>1 is 0 mod 8.)
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const int cq = q ^ ((r0 >> 1) & 7);
+    const int cq = q ^ (r0 & 7);
     typedef __attribute__((address_space(3))) void lds_void;
     auto dma = [&](int stage, int tap, int cc) {
         const int c = cc * BKE + cq * EPC;
@@ -151,12 +160,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
                     const int r = wm * (MI * 16) + mi * 16 + fr;
-                    xa[mi] = *reinterpret_cast<const f16x8*>(A + r * 128 + ((qf ^ ((r >> 1) & 7)) << 4));
+                    xa[mi] = *reinterpret_cast<const f16x8*>(A + r * 128 + ((qf ^ (r & 7)) << 4));
                 }
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) {
                     const int r = wn * 64 + ni * 16 + fr;
-                    wb[ni] = *reinterpret_cast<const f16x8*>(Bm + r * 128 + ((qf ^ ((r >> 1) & 7)) << 4));
+                    wb[ni] = *reinterpret_cast<const f16x8*>(Bm + r * 128 + ((qf ^ (r & 7)) << 4));
                 }
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni)
@@ -171,12 +180,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
                     const int r = wm * (MI * 16) + mi * 16 + fr;
-                    xa[mi] = *reinterpret_cast<const float*>(A + r * 128 + ((ks ^ ((r >> 1) & 7)) << 4) + fq * 4);
+                    xa[mi] = *reinterpret_cast<const float*>(A + r * 128 + ((ks ^ (r & 7)) << 4) + fq * 4);
                 }
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) {
                     const int r = wn * 64 + ni * 16 + fr;
-                    wb[ni] = *reinterpret_cast<const float*>(Bm + r * 128 + ((ks ^ ((r >> 1) & 7)) << 4) + fq * 4);
+                    wb[ni] = *reinterpret_cast<const float*>(Bm + r * 128 + ((ks ^ (r & 7)) << 4) + fq * 4);
                 }
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni)
@@ -315,7 +324,7 @@ __global__ __launch_bounds__(WM * 128) void conv3x3_halo_kernel(const ConvArgs a
         const int r = wi * 8 + (lane >> 3);
         const int ry = r / (TW + 2), rx = r - ry * (TW + 2);
         const int y = y0 + ry - 1, x = x0 + rx - 1;
-        const int q = (lane & 7) ^ ((r >> 1) & 7);
+        const int q = (lane & 7) ^ (r & 7);
         const bool ok = r < PR && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
         poff[j] = ok ? (unsigned)(((b * H + y) * W + x) * a.in0_ct + a.in0_coff + q * 8) * 2u : CY_OOB;
     }
@@ -323,7 +332,7 @@ __global__ __launch_bounds__(WM * 128) void conv3x3_halo_kernel(const ConvArgs a
 #pragma unroll
     for (int j = 0; j < WROUNDS; ++j) {
         const int row = (j * NW + wave) * 8 + (lane >> 3);
-        const int q = (lane & 7) ^ ((row >> 1) & 7);
+        const int q = (lane & 7) ^ (row & 7);
         woff[j] = (unsigned)((n0 + row) * 9 * a.Cin + q * 8) * 2u;
     }
     auto dma_patch = [&](int buf, int ch) {
@@ -357,12 +366,12 @@ __global__ __launch_bounds__(WM * 128) void conv3x3_halo_kernel(const ConvArgs a
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
                 const int r = (wm * 4 + mi + kh) * (TW + 2) + kw + fr;
-                xa[mi] = *reinterpret_cast<const f16x8*>(P + r * 128 + ((qf ^ ((r >> 1) & 7)) << 4));
+                xa[mi] = *reinterpret_cast<const f16x8*>(P + r * 128 + ((qf ^ (r & 7)) << 4));
             }
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
                 const int r = wn * 64 + ni * 16 + fr;
-                wb[ni] = *reinterpret_cast<const f16x8*>(Wb + r * 128 + ((qf ^ ((r >> 1) & 7)) << 4));
+                wb[ni] = *reinterpret_cast<const f16x8*>(Wb + r * 128 + ((qf ^ (r & 7)) << 4));
             }
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
@@ -382,23 +391,42 @@ __global__ __launch_bounds__(WM * 128) void conv3x3_halo_kernel(const ConvArgs a
     if (DIST > 1 && total > 1) { w_issue(1); CY_WAIT_VM((DIST - 1) * WROUNDS); } else { CY_WAIT_VM(0); }
     __builtin_amdgcn_s_barrier();
     int it = 0;
+    const bool stamps = (a.dbg & 64) != 0;
+    unsigned long long acc_dma = 0, acc_cmp = 0, acc_wait = 0, acc_bar = 0;
+    const unsigned long long t_begin = stamps ? stamp_now() : 0;
     for (int ch = 0; ch < chunks; ++ch) {
         const char* P = Pbuf + (ch & 1) * P_BYTES;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap, ++it) {
             const bool pre_p = tap == 0 && ch + 1 < chunks, pre_w = it + DIST < total;
+            unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+            if (stamps) { __builtin_amdgcn_sched_barrier(0); t0 = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
             if (pre_p) dma_patch((ch + 1) & 1, ch + 1);
             if (pre_w) w_issue(it + DIST);
+            if (stamps) { __builtin_amdgcn_sched_barrier(0); t1 = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
             const int kh = tap / 3, kw = tap - kh * 3;
             compute(P, Wbuf + (it % RING) * W_BYTES, kh, kw);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this tap's fragment reads are done (WAR on the ring)
+            if (stamps) { __builtin_amdgcn_sched_barrier(0); t2 = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
             if (pre_w && DIST > 1) { CY_WAIT_VM((DIST - 1) * WROUNDS); }   // all but the newest slab request have landed
             else { CY_WAIT_VM(0); }
+            if (stamps) { __builtin_amdgcn_sched_barrier(0); t3 = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
+            if (stamps) {
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned long long t4 = stamp_now();
+                acc_dma += t1 - t0; acc_cmp += t2 - t1; acc_wait += t3 - t2; acc_bar += t4 - t3;
+            }
         }
     }
 
+    if (stamps && lane == 0) {
+        const unsigned long long t_end = stamp_now();
+        atomicAdd(&g_stamps[0], acc_dma); atomicAdd(&g_stamps[1], acc_cmp); atomicAdd(&g_stamps[2], acc_wait);
+        atomicAdd(&g_stamps[3], acc_bar); atomicAdd(&g_stamps[4], t_end - t_begin); atomicAdd(&g_stamps[5], (unsigned long long)total);
+        atomicAdd(&g_stamps[6], 1ull);
+    }
     // ---- epilogue (same per-lane channel layout as the generic kernel)
     const int cbase = n0 + wn * 64 + fq * 16;
     float bv[16];
@@ -492,7 +520,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(const ConvArgs a) {
         const int r = (j * NW + wave) * 8 + (lane >> 3);
         const int ry = r / (TW + 2), rx = r - ry * (TW + 2);
         const int y = y0 + ry - 1, x = x0 + rx - 1;
-        const int q = (lane & 7) ^ ((r >> 1) & 7);
+        const int q = (lane & 7) ^ (r & 7);
         const bool ok = r < PR && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
         poff[j] = ok ? (unsigned)(((b * H + y) * W + x) * a.in0_ct + a.in0_coff + q * 8) * 2u : CY_OOB;
     }
@@ -500,7 +528,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(const ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < WROUNDS; ++j) {
         const int row = ((j * NW + wave) % WPIECES) * 8 + (lane >> 3);
-        const int q = (lane & 7) ^ ((row >> 1) & 7);
+        const int q = (lane & 7) ^ (row & 7);
         woff[j] = (unsigned)((n0 + row) * 9 * a.Cin + q * 8) * 2u;
     }
     auto dma_patch = [&](int buf, int ch) {
@@ -535,12 +563,12 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(const ConvArgs a) {
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
             const int r = (wm * 4 + mi + kh) * (TW + 2) + kw + fr;
-            xa[mi] = *reinterpret_cast<const f16x8*>(P + r * 128 + ((qf ^ ((r >> 1) & 7)) << 4));
+            xa[mi] = *reinterpret_cast<const f16x8*>(P + r * 128 + ((qf ^ (r & 7)) << 4));
         }
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             const int r = wn * (NI * 16) + ni * 16 + fr;
-            wb[ni] = *reinterpret_cast<const f16x8*>(Wb + r * 128 + ((qf ^ ((r >> 1) & 7)) << 4));
+            wb[ni] = *reinterpret_cast<const f16x8*>(Wb + r * 128 + ((qf ^ (r & 7)) << 4));
         }
     };
     auto mfma_all = [&](const f16x8* xa, const f16x8* wb) {
@@ -688,7 +716,7 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const ConvArgs a) {
         for (int j = 0; j < 18; ++j) {
             const int pc = j * NW + wave;                   // 72 pieces of 8 rows: piece = tap*8 + row block
             const int tap = pc >> 3, row = (pc & 7) * 8 + (lane >> 3);
-            const int q = (lane & 7) ^ ((row >> 1) & 7);
+            const int q = (lane & 7) ^ (row & 7);
             const unsigned off = (unsigned)((row * 9 + tap) * 64 + q * 8) * 2u;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)(Wl + pc * 1024), 16, off, 0, 0, 0);
         }
@@ -707,7 +735,7 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const ConvArgs a) {
             const int r = wi * 8 + (lane >> 3);
             const int ry = r / (TW + 2), rx = r - ry * (TW + 2);
             const int y = y0 + ry - 1, x = x0 + rx - 1;
-            const int q = (lane & 7) ^ ((r >> 1) & 7);
+            const int q = (lane & 7) ^ (r & 7);
             const bool ok = r < PR && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
             const unsigned off = ok ? (unsigned)(((b * H + y) * W + x) * a.in0_ct + a.in0_coff + q * 8) * 2u : CY_OOB;
             char* dst = Pl + buf * P_BYTES + (wi < NWI ? wi : NWI) * 1024;
@@ -739,11 +767,11 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) {
                     const int r = (wm * 4 + mi + kh) * (TW + 2) + kw + fr;
-                    xa[mi] = *reinterpret_cast<const f16x8*>(P + r * 128 + ((qf ^ ((r >> 1) & 7)) << 4));
+                    xa[mi] = *reinterpret_cast<const f16x8*>(P + r * 128 + ((qf ^ (r & 7)) << 4));
                 }
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
-                    wb[ni] = *reinterpret_cast<const f16x8*>(Wl + (tap * 64 + ni * 16 + fr) * 128 + ((qf ^ ((fr >> 1) & 7)) << 4));
+                    wb[ni] = *reinterpret_cast<const f16x8*>(Wl + (tap * 64 + ni * 16 + fr) * 128 + ((qf ^ (fr & 7)) << 4));
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -874,10 +902,16 @@ hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s) {
         case CONV_PP_64: return launch_pp<2>(a, s);
         case CONV_PP_128: { ConvArgs b2 = a; b2.dbg = getenv("CY_DBG") ? atoi(getenv("CY_DBG")) : 0; return launch_pp<4>(b2, s); }
         case CONV_HALO16_128: return (getenv("CY_HALO_WM") && atoi(getenv("CY_HALO_WM")) == 43) ? launch_halo<4, 3>(a, s) : launch_halo<4, 2>(a, s);
-        case CONV_HALO8_128: return launch_halo<2, 2>(a, s);
+        case CONV_HALO8_128: { ConvArgs b2 = a; b2.dbg = getenv("CY_DBG") ? atoi(getenv("CY_DBG")) : 0; return launch_halo<2, 2>(b2, s); }
         case CONV_GENERIC_64: return p == PREC_F16 ? launch_t<f16, 4, 1, 2>(a, s) : launch_t<float, 4, 1, 2>(a, s);
         default: return p == PREC_F16 ? launch_t<f16, 2, 2, 4>(a, s) : launch_t<float, 2, 2, 4>(a, s);
     }
+}
+
+void debug_read_stamps(unsigned long long* out8, bool reset) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stamps), 8 * sizeof(unsigned long long));
+    if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)); }
 }
 
 // ------------------------------------------------------------------------------------------------ weights

@@ -501,6 +501,8 @@ int cy_conv_bn_silu(cy_ctx* c, const void* d_in, int B, int Hi, int Wi, int Cin,
     return CY_OK;
 }
 
+int cy_debug_stamps(unsigned long long* out8, int reset) { if (!out8) return CY_ERR_ARG; debug_read_stamps(out8, reset != 0); return CY_OK; }
+
 int cy_debug_cand_counts(cy_ctx* c, int* h_out, int B) {
     if (!c || !c->loaded || !h_out || B < 1 || B > c->cfg.max_batch) return fail(c, CY_ERR_ARG, "bad arguments");
     HIPCHK(c, hipDeviceSynchronize());

@@ -155,9 +155,15 @@ class TileEngine(object):
         det = rows[:, :L.CY_MAX_DET * 6].reshape(-1, L.CY_MAX_DET, 6)[keep]          # [Ndet, 6] in tile-id order
         dtile = torch.repeat_interleave(tid, cnt)
         stats = {"tiles": int(rows.shape[0]), "skipped": int((status != 0).sum()), "per_tile_detections": int(cnt.sum())}
+        import time as _t
+        t0 = _t.time()
         det_h = np.ascontiguousarray(det.cpu().numpy(), np.float32)
         dtile_h = np.ascontiguousarray(dtile.cpu().numpy().astype(np.int32))
-        return merge_records(det_h, dtile_h, self.grid), stats
+        t1 = _t.time()
+        out = merge_records(det_h, dtile_h, self.grid)
+        stats["merge_host_ms"] = 1e3 * (_t.time() - t1)
+        stats["merge_d2h_ms"] = 1e3 * (t1 - t0)
+        return out, stats
 
     def catalog(self, names):
         """-> (the reference's list of source dicts, stats)."""

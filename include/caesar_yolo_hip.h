@@ -110,6 +110,8 @@ int cy_debug_read_conv(cy_ctx* ctx, const char* conv_name, float* h_out, size_t 
 int cy_decode_nms(cy_ctx* ctx, const float* d_pred, int B, int H, int W, int h0, int w0, float conf, float iou,
                   float* d_det, int* d_det_anchor, int* d_count, void* stream);
 
+/* developer diagnostics: in-kernel cycle stamps of the 3x3 halo kernel (enabled with CY_DBG=64) */
+int cy_debug_stamps(unsigned long long* out8, int reset);
 /* number of pre-NMS candidates per tile of the last cy_decode_nms call (diagnostics) */
 int cy_debug_cand_counts(cy_ctx* ctx, int* h_out, int B);
 
