@@ -62,6 +62,31 @@ def cpu_baseline(mosaic_host, grid, names_w, budget_s=20.0, max_tiles=24):
                       "fp32 yolov8l + NMS + IoU merge, %.1f s" % (done, sample[0], dt)}
 
 
+def pmc_traffic(kernel_label):
+    """HBM bytes per launch of the dominant kernel from the tracked rocprofv3 PMC passes (profiles/*_hbm_traffic.json,
+    collected by tools/collect_profiles.sh on this same command line); None if no profile has been recorded."""
+    import glob
+
+    def family(n):
+        n = n.replace(" ", "")
+        for fam in ("conv3x3_halo_kernel", "conv3x3_pp_kernel", "conv3x3_c64_kernel", "stem_mfma_kernel"):
+            if fam in n:
+                return fam
+        if "conv_igemm_kernel" in n:
+            return "conv_igemm_kernel<2,2,4>" if ("<2,2,4>" in n or "Li2ELi2ELi4E" in n) else "conv_igemm_kernel<4,1,2>"
+        return None
+    want, best = family(kernel_label), None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json"))):
+        try:
+            t = json.load(open(f))
+        except Exception:
+            continue
+        for name, v in t.items():
+            if want and family(name) == want:
+                best = v["hbm_bytes_per_launch"]
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -183,7 +208,7 @@ def main():
             if k["launches"] and k["ms"] > 0:
                 ach = k["flops"] / (k["ms"] * 1e-3) / 1e12
                 out["roofline"] = {"kernel": k["kernel"], "bound": "mfma", "achieved": ach, "peak": PEAK_FP16_DENSE_TFLOPS,
-                                   "unit": "TFLOP/s", "frac": ach / PEAK_FP16_DENSE_TFLOPS, "traffic": None,
+                                   "unit": "TFLOP/s", "frac": ach / PEAK_FP16_DENSE_TFLOPS, "traffic": pmc_traffic(k["kernel"]),
                                    "flops_per_launch": k["flops"] / k["launches"],
                                    "avg_launch_ms": k["ms"] / k["launches"], "launches": k["launches"],
                                    "timing": "hipEvents around every launch on the launch stream, over the timed region (rank 0)"}

@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
 // ragged image edges comes from the buffer range check, as in the generic kernel.
 #define CY_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
-template <int WM, int RING>
+template <int WM, int RING, int PB = 2>
 __global__ __launch_bounds__(WM * 128) void conv3x3_halo_kernel(const ConvArgs a) {
     constexpr int TH = 4 * WM, TW = 16, NT = WM * 128, NW = NT / 64, BN = 128;
     constexpr int PR = (TH + 2) * (TW + 2);                 // halo rows (one row = one pixel, 64 channels = 128 B)
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(WM * 128) void conv3x3_halo_kernel(const ConvArgs a
     constexpr int DIST = RING - 1;                           // weight slabs in flight: tap t+DIST is fetched while tap t computes
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const Pbuf = smem;
-    char* const Wbuf = smem + 2 * P_BYTES;               // [halo 0 | halo 1 | weight ring]
+    char* const Wbuf = smem + PB * P_BYTES;              // [halo 0 (| halo 1) | weight ring]
     typedef __attribute__((address_space(3))) void lds_void;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -395,10 +395,17 @@ __global__ __launch_bounds__(WM * 128) void conv3x3_halo_kernel(const ConvArgs a
     unsigned long long acc_dma = 0, acc_cmp = 0, acc_wait = 0, acc_bar = 0;
     const unsigned long long t_begin = stamps ? stamp_now() : 0;
     for (int ch = 0; ch < chunks; ++ch) {
-        const char* P = Pbuf + (ch & 1) * P_BYTES;
+        const char* P = Pbuf + (PB == 2 ? (ch & 1) : 0) * P_BYTES;
+        if (PB == 1 && ch > 0) {
+            // single halo buffer: every wave is past the last tap's barrier, so the buffer is free; fetch the next
+            // 64-channel halo now and wait for it (once per nine taps) -- the LDS saved buys a third weight slot
+            dma_patch(0, ch);
+            CY_WAIT_VM(0);
+            __builtin_amdgcn_s_barrier();
+        }
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap, ++it) {
-            const bool pre_p = tap == 0 && ch + 1 < chunks, pre_w = it + DIST < total;
+            const bool pre_p = PB == 2 && tap == 0 && ch + 1 < chunks, pre_w = it + DIST < total;
             unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
             if (stamps) { __builtin_amdgcn_sched_barrier(0); t0 = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
             if (pre_p) dma_patch((ch + 1) & 1, ch + 1);
@@ -840,18 +847,18 @@ static hipError_t launch_c64(const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int WM, int RING>
+template <int WM, int RING, int PB = 2>
 static hipError_t launch_halo(const ConvArgs& a, hipStream_t s) {
     constexpr int TH = 4 * WM, NT = WM * 128;
     constexpr int PR = (TH + 2) * 18, NWI = (PR + 7) / 8, NW = NT / 64, PROUNDS = (NWI + NW - 1) / NW;
-    const size_t lds = 2 * PROUNDS * NW * 1024 + RING * 128 * 128;
+    const size_t lds = PB * PROUNDS * NW * 1024 + RING * 128 * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<WM, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<WM, RING, PB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const int blocks = a.B * ((a.Hi + TH - 1) / TH) * ((a.Wi + 15) / 16) * ((pad64(a.Cout) + 127) / 128);
-    hipLaunchKernelGGL((conv3x3_halo_kernel<WM, RING>), dim3(blocks), dim3(NT), lds, s, a);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<WM, RING, PB>), dim3(blocks), dim3(NT), lds, s, a);
     return hipGetLastError();
 }
 
@@ -902,7 +909,11 @@ hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s) {
         case CONV_PP_64: return launch_pp<2>(a, s);
         case CONV_PP_128: { ConvArgs b2 = a; b2.dbg = getenv("CY_DBG") ? atoi(getenv("CY_DBG")) : 0; return launch_pp<4>(b2, s); }
         case CONV_HALO16_128: return (getenv("CY_HALO_WM") && atoi(getenv("CY_HALO_WM")) == 43) ? launch_halo<4, 3>(a, s) : launch_halo<4, 2>(a, s);
-        case CONV_HALO8_128: { ConvArgs b2 = a; b2.dbg = getenv("CY_DBG") ? atoi(getenv("CY_DBG")) : 0; return launch_halo<2, 2>(b2, s); }
+        case CONV_HALO8_128: {
+            ConvArgs b2 = a; b2.dbg = getenv("CY_DBG") ? atoi(getenv("CY_DBG")) : 0;
+            static const int v = getenv("CY_HALO_V") ? atoi(getenv("CY_HALO_V")) : 0;
+            return v == 1 ? launch_halo<2, 3, 1>(b2, s) : launch_halo<2, 2>(b2, s);
+        }
         case CONV_GENERIC_64: return p == PREC_F16 ? launch_t<f16, 4, 1, 2>(a, s) : launch_t<float, 4, 1, 2>(a, s);
         default: return p == PREC_F16 ? launch_t<f16, 2, 2, 4>(a, s) : launch_t<float, 2, 2, 4>(a, s);
     }

@@ -1,0 +1,72 @@
+"""Turn the raw rocprofv3 CSVs collected by tools/collect_profiles.sh into the tracked summaries under profiles/.
+python tools/summarize_profiles.py r01"""
+import csv, glob, json, os, sys, collections
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+G = os.path.join(ROOT, "gpurun_out")
+P = os.path.join(ROOT, "profiles")
+os.makedirs(P, exist_ok=True)
+
+
+def short(n):
+    return n.replace("void ", "").replace("cy::", "").split("(")[0][:70]
+
+
+def pmc(dirname, counters):
+    f = glob.glob(os.path.join(G, dirname, "*", "*counter_collection.csv"))
+    out = collections.defaultdict(lambda: collections.defaultdict(float))
+    cnt = collections.Counter()
+    if not f:
+        return out, cnt
+    for r in csv.DictReader(open(f[0])):
+        if r["Counter_Name"] in counters:
+            k = short(r["Kernel_Name"])
+            out[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            if r["Counter_Name"] == counters[0]:
+                cnt[k] += 1
+    return out, cnt
+
+
+stats = glob.glob(os.path.join(G, tag + "_ktrace", "*", "*kernel_stats.csv"))
+rows = list(csv.DictReader(open(stats[0]))) if stats else []
+with open(os.path.join(P, tag + "_final_kernel_stats.csv"), "w") as fp:
+    if stats:
+        fp.write(open(stats[0]).read())
+bench = json.load(open(os.path.join(G, tag + "_bench.json")))
+json.dump(bench, open(os.path.join(P, tag + "_final_bench_N1.json"), "w"), indent=1)
+fetch, nf = pmc(tag + "_pmc_fetch", ["FETCH_SIZE"])
+write, nw = pmc(tag + "_pmc_write", ["WRITE_SIZE"])
+traffic = {}
+for k in fetch:
+    if nf[k] and k in write and nw[k]:
+        f_kb, w_kb = fetch[k]["FETCH_SIZE"] / nf[k], write[k]["WRITE_SIZE"] / nw[k]
+        # MI355X_MICROARCH.md, HBM section: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-byte
+        # requests as 64 bytes for wide coalesced reads -> doubled; WRITE_SIZE is exact for 16-byte-per-lane stores
+        traffic[k] = {"launches": nf[k], "FETCH_SIZE_KiB_per_launch": f_kb, "WRITE_SIZE_KiB_per_launch": w_kb,
+                      "hbm_bytes_per_launch": (2.0 * f_kb + w_kb) * 1024.0}
+json.dump(traffic, open(os.path.join(P, tag + "_final_hbm_traffic.json"), "w"), indent=1)
+sq, nsq = pmc(tag + "_pmc_sq", ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
+                                "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"])
+with open(os.path.join(P, tag + "_final_summary.md"), "w") as fp:
+    fp.write("# %s final profile (1x MI355X, default `python bench.py`)\n\n" % tag)
+    fp.write("bench line: %.1f tiles/s, %.1f ms/step; dominant kernel `%s` %.1f TFLOP/s (%.3f of 2.5 PFLOP/s), avg launch %.4f ms\n\n"
+             % (bench["value"], bench["ms_per_step"], bench["roofline"]["kernel"], bench["roofline"]["achieved"],
+                bench["roofline"]["frac"], bench["roofline"]["avg_launch_ms"]))
+    fp.write("## rocprofv3 --kernel-trace --stats (bench.py --steps 1 --warmup 1: two passes over the 1600-tile grid)\n\n")
+    fp.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
+    for r in rows[:16]:
+        fp.write("| `%s` | %s | %.2f | %.1f | %s |\n" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+                                                     float(r["AverageNs"]) / 1e3, r["Percentage"]))
+    fp.write("\n## HBM traffic per launch (separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied)\n\n")
+    fp.write("| kernel | launches | 2*FETCH_SIZE MiB | WRITE_SIZE MiB | total MiB/launch |\n|---|---|---|---|---|\n")
+    for k, v in sorted(traffic.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:12]:
+        fp.write("| `%s` | %d | %.1f | %.1f | %.1f |\n" % (k, v["launches"], 2 * v["FETCH_SIZE_KiB_per_launch"] / 1024,
+                                                        v["WRITE_SIZE_KiB_per_launch"] / 1024, v["hbm_bytes_per_launch"] / 2 ** 20))
+    fp.write("\n## SQ counters (bench.py --size 8192, one pass; sums over the dispatches of each kernel)\n\n")
+    fp.write("| kernel | n | MFMA busy / (4 x BUSY_CU-ish) | WAIT_ANY/WAVE | WAIT_INST/WAVE | ACTIVE/WAVE | LDS conflict / LDS active |\n|---|---|---|---|---|---|---|\n")
+    for k, v in sorted(sq.items(), key=lambda kv: -kv[1].get("SQ_BUSY_CYCLES", 0))[:10]:
+        wv = max(v.get("SQ_WAVE_CYCLES", 0), 1)
+        fp.write("| `%s` | %d | %.3g | %.2f | %.2f | %.2f | %.2f |\n" % (
+            k, nsq[k], v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0), v.get("SQ_WAIT_ANY", 0) / wv, v.get("SQ_WAIT_INST_ANY", 0) / wv,
+            v.get("SQ_ACTIVE_INST_ANY", 0) / wv, v.get("SQ_LDS_BANK_CONFLICT", 0) / max(v.get("SQ_LDS_IDX_ACTIVE", 0), 1)))
+print(open(os.path.join(P, tag + "_final_summary.md")).read())
