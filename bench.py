@@ -69,7 +69,7 @@ def pmc_traffic(kernel_label):
 
     def family(n):
         n = n.replace(" ", "")
-        for fam in ("conv3x3_halo_kernel", "conv3x3_pp_kernel", "conv3x3_c64_kernel", "stem_mfma_kernel"):
+        for fam in ("conv3x3_halo2_kernel", "conv3x3_halo_kernel", "conv3x3_pp_kernel", "conv3x3_c64_kernel", "stem_mfma_kernel"):
             if fam in n:
                 return fam
         if "conv_igemm_kernel" in n:

@@ -847,6 +847,183 @@ static hipError_t launch_c64(const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ 3x3 s1, two taps per barrier
+// Variant of conv3x3_halo_kernel for 16x16-pixel patches (8 waves, one workgroup per CU, all 160 KiB of LDS): a pipeline
+// stage holds the weight slabs of TWO taps, so a wave issues 64 MFMAs between barriers instead of 32 and the per-stage
+// cost (DMA issue, vmcnt drain, s_barrier: ~600 cycles in the stamped build) is paid half as often.  Input channels are
+// walked in pairs of 64-channel slabs (18 taps = 9 stages, fully unrolled, so every fragment address is a constant
+// offset); the two halo buffers hold the even / odd slab of the pair and are refilled as soon as their last tap is done.
+__global__ __launch_bounds__(512) void conv3x3_halo2_kernel(const ConvArgs a) {
+    constexpr int TH = 16, TW = 16, NW = 8, BN = 128;
+    constexpr int PR = (TH + 2) * (TW + 2), NWI = (PR + 7) / 8, PROUNDS = (NWI + NW - 1) / NW;
+    constexpr int P_BYTES = PROUNDS * NW * 1024, SLAB = BN * 128, W_BYTES = 2 * SLAB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const Pbuf = smem;
+    char* const Wbuf = smem + 2 * P_BYTES;
+    typedef __attribute__((address_space(3))) void lds_void;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int H = a.Hi, W = a.Wi;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int ntn = (pad64(a.Cout) + BN - 1) / BN;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = id % ntn;
+    int rest = id / ntn;
+    const int tx = rest % tiles_x; rest /= tiles_x;
+    const int ty = rest % tiles_y;
+    const int b = rest / tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW, n0 = nt * BN;
+    const int chunks = a.Cin / 64, pairs = chunks / 2;      // launch_conv guarantees an even number of slabs
+
+    const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in0), 0, a.in0_bytes, 0x00020000);
+    const auto rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wgt), 0, a.wgt_bytes, 0x00020000);
+    unsigned poff[PROUNDS];
+#pragma unroll
+    for (int j = 0; j < PROUNDS; ++j) {
+        const int r = (j * NW + wave) * 8 + (lane >> 3);
+        const int ry = r / (TW + 2), rx = r - ry * (TW + 2);
+        const int y = y0 + ry - 1, x = x0 + rx - 1;
+        const int q = (lane & 7) ^ (r & 7);
+        const bool ok = r < PR && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+        poff[j] = ok ? (unsigned)(((b * H + y) * W + x) * a.in0_ct + a.in0_coff + q * 8) * 2u : CY_OOB;
+    }
+    unsigned woff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (j * NW + wave) * 8 + (lane >> 3);
+        woff[j] = (unsigned)((n0 + row) * 9 * a.Cin + ((lane & 7) ^ (row & 7)) * 8) * 2u;
+    }
+    auto dma_patch = [&](int buf, int ch) {
+#pragma unroll
+        for (int j = 0; j < PROUNDS; ++j) {
+            const unsigned off = poff[j] == CY_OOB ? CY_OOB : poff[j] + (unsigned)(ch * 128);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_void*)(Pbuf + buf * P_BYTES + (j * NW + wave) * 1024), 16, off, 0, 0, 0);
+        }
+    };
+    auto dma_slab = [&](int buf, int t, int ch, int tap) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const unsigned off = woff[j] + (unsigned)((tap * a.Cin + ch * 64) * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)(Wbuf + buf * W_BYTES + t * SLAB + (j * NW + wave) * 1024), 16, off, 0, 0, 0);
+        }
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+    auto compute = [&](const char* P, const char* Wb, int kh, int kw) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int qf = fq + 4 * kk;
+            f16x8 xa[4], wb[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int r = (wm * 4 + mi + kh) * (TW + 2) + kw + fr;
+                xa[mi] = *reinterpret_cast<const f16x8*>(P + r * 128 + ((qf ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int r = wn * 64 + ni * 16 + fr;
+                wb[ni] = *reinterpret_cast<const f16x8*>(Wb + r * 128 + ((qf ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0);
+        }
+    };
+
+    // prologue: halo of slab 0, weight stage 0 (taps 0,1 of slab 0)
+    dma_patch(0, 0);
+    dma_slab(0, 0, 0, 0);
+    dma_slab(0, 1, 0, 1);
+    __syncthreads();
+    int g = 0;                                               // global stage counter: weight stage buffer = g & 1
+#pragma unroll 1
+    for (int cp = 0; cp < pairs; ++cp) {
+#pragma unroll
+        for (int st = 0; st < 9; ++st, ++g) {
+            // requests for the next stage / the halo buffers that have just become free
+            if (st < 8) {
+                const int u0 = 2 * (st + 1), u1 = u0 + 1;
+                dma_slab((g + 1) & 1, 0, 2 * cp + u0 / 9, u0 % 9);
+                dma_slab((g + 1) & 1, 1, 2 * cp + u1 / 9, u1 % 9);
+            } else if (cp + 1 < pairs) {
+                dma_slab((g + 1) & 1, 0, 2 * cp + 2, 0);
+                dma_slab((g + 1) & 1, 1, 2 * cp + 2, 1);
+            }
+            if (st == 0) dma_patch(1, 2 * cp + 1);                                  // odd slab of this pair (needed from stage 4)
+            if (st == 5 && cp + 1 < pairs) dma_patch(0, 2 * cp + 2);                // even slab of the next pair
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int u = 2 * st + t, tap = u % 9;
+                compute(Pbuf + (u / 9) * P_BYTES, Wbuf + (g & 1) * W_BYTES + t * SLAB, tap / 3, tap % 3);
+            }
+            __syncthreads();
+        }
+    }
+
+    const int cbase = n0 + wn * 64 + fq * 16;
+    float bv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) bv[j] = a.bias[cbase + j];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int y = y0 + wm * 4 + mi, x = x0 + fr;
+        if (y >= H || x >= W) continue;
+        const long pix = ((long)b * H + y) * W + x;
+        float v[16];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float t = acc[ni][mi][j] + bv[ni * 4 + j];
+                if (a.act) t = silu_fast(t);
+                v[ni * 4 + j] = t;
+            }
+        if (cbase + 16 <= a.Cout) {
+            f16* dst = reinterpret_cast<f16*>(a.out) + pix * a.out_ct + a.out_coff + cbase;
+            if (a.res) {
+                const f16* rp = reinterpret_cast<const f16*>(a.res) + pix * a.res_ct + a.res_coff + cbase;
+                const f16x8 r0v = *reinterpret_cast<const f16x8*>(rp), r1v = *reinterpret_cast<const f16x8*>(rp + 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { v[j] += (float)r0v[j]; v[8 + j] += (float)r1v[j]; }
+            }
+            f16x8 o0, o1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { o0[j] = (f16)v[j]; o1[j] = (f16)v[8 + j]; }
+            *reinterpret_cast<f16x8*>(dst) = o0;
+            *reinterpret_cast<f16x8*>(dst + 8) = o1;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int c = cbase + j;
+                if (c >= a.Cout) continue;
+                float t = v[j];
+                if (a.res) t += (float)(reinterpret_cast<const f16*>(a.res)[pix * a.res_ct + a.res_coff + c]);
+                reinterpret_cast<f16*>(a.out)[pix * a.out_ct + a.out_coff + c] = (f16)t;
+            }
+        }
+    }
+}
+
+static hipError_t launch_halo2(const ConvArgs& a, hipStream_t s) {
+    constexpr int NWI = (18 * 18 + 7) / 8, PROUNDS = (NWI + 7) / 8;
+    const size_t lds = 2 * PROUNDS * 8 * 1024 + 2 * 2 * 128 * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int blocks = a.B * ((a.Hi + 15) / 16) * ((a.Wi + 15) / 16) * ((pad64(a.Cout) + 127) / 128);
+    hipLaunchKernelGGL(conv3x3_halo2_kernel, dim3(blocks), dim3(512), lds, s, a);
+    return hipGetLastError();
+}
+
 template <int WM, int RING, int PB = 2>
 static hipError_t launch_halo(const ConvArgs& a, hipStream_t s) {
     constexpr int TH = 4 * WM, NT = WM * 128;
@@ -881,7 +1058,7 @@ static hipError_t launch_t(const ConvArgs& a, hipStream_t s) {
 // Kernel variants (also the keys of the profiling summary)
 static const char* const kVariantNames[CONV_NUM_VARIANTS] = {
     "conv_igemm_kernel<2,2,4> generic 128x128", "conv_igemm_kernel<4,1,2> generic 128x64",
-    "conv3x3_halo_kernel<2,2> 3x3 s1 8x16px x128ch", "conv3x3_pp_kernel<2> 3x3 s1 16x16px x64ch",
+    "conv3x3_halo2_kernel 3x3 s1 16x16px x128ch (halo<2,2> for odd slab counts)", "conv3x3_pp_kernel<2> 3x3 s1 16x16px x64ch",
     "conv3x3_pp_kernel<4> 3x3 s1 16x16px x128ch", "conv3x3_halo_kernel<4,*> 3x3 s1 16x16px x128ch",
     "conv3x3_c64_kernel 3x3 s1 64->64 persistent"};
 const char* conv_variant_name(int v) { return v >= 0 && v < CONV_NUM_VARIANTS ? kVariantNames[v] : "?"; }
@@ -911,7 +1088,8 @@ hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s) {
         case CONV_HALO16_128: return (getenv("CY_HALO_WM") && atoi(getenv("CY_HALO_WM")) == 43) ? launch_halo<4, 3>(a, s) : launch_halo<4, 2>(a, s);
         case CONV_HALO8_128: {
             ConvArgs b2 = a; b2.dbg = getenv("CY_DBG") ? atoi(getenv("CY_DBG")) : 0;
-            static const int v = getenv("CY_HALO_V") ? atoi(getenv("CY_HALO_V")) : 0;
+            static const int v = getenv("CY_HALO_V") ? atoi(getenv("CY_HALO_V")) : 2;      // 2: two taps per barrier (default)
+            if (v == 2 && (a.Cin / 64) % 2 == 0) return launch_halo2(b2, s);
             return v == 1 ? launch_halo<2, 3, 1>(b2, s) : launch_halo<2, 2>(b2, s);
         }
         case CONV_GENERIC_64: return p == PREC_F16 ? launch_t<f16, 4, 1, 2>(a, s) : launch_t<float, 4, 1, 2>(a, s);
