@@ -215,8 +215,10 @@ int cy_create(int device, const cy_config* cfg, cy_ctx** out) {
         return fail(nullptr, CY_ERR_ARG, "max_batch >= 1 and max_h/max_w multiples of 32 required");
     if (cfg->precision != CY_F16 && cfg->precision != CY_F32) return fail(nullptr, CY_ERR_ARG, "bad precision");
     int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n)
-        return fail(nullptr, CY_ERR_HIP, "no such HIP device (this library has no CPU fallback)");
+    const hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || device < 0 || device >= n)
+        return fail(nullptr, CY_ERR_HIP, std::string("no such HIP device (this library has no CPU fallback): hipGetDeviceCount -> ") +
+                                             hipGetErrorString(e) + ", " + std::to_string(n) + " device(s), requested " + std::to_string(device));
     cy_ctx* c = new cy_ctx();
     c->device = device; c->cfg = *cfg; c->prec = cfg->precision == CY_F16 ? PREC_F16 : PREC_F32;
     *out = c;

@@ -65,6 +65,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch (device memory / streams for this package) bundles its own HIP runtime.  It must be the one already mapped
+    # when libcaesar_yolo_hip.so resolves libamdhip64: two HIP runtimes in one process do not both see the GPU.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise CyError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                       "(there is no CPU fallback)" % LIB_PATH)
