@@ -65,3 +65,27 @@ def test_forward_ragged_letterboxed_shape_fp32():
     torch.cuda.synchronize()
     err = float((pred.cpu() - raw).abs().max())
     assert err <= 2e-4 * max(1.0, float(raw.abs().max())), err
+
+
+@pytest.mark.parametrize("scale,nc", [("n", 5), ("s", 3)])
+def test_other_scales_fp32(scale, nc):
+    """yolov8n / yolov8s graphs (16..512 channels, slabs that are not multiples of 64) through the same kernels."""
+    from caesar_yolo_amd import weights as W
+    from caesar_yolo_amd.model import HipDetector
+    from oracle import yolov8_ref as Y
+    path = "/tmp/cy_test_seeded_%s_%d.cyw" % (scale, nc)
+    if not os.path.exists(path):
+        W.make_seeded_file(path, scale, nc)
+    sc, names, wd, _ = W.read_cyw(path)
+    for prec, tol in (("fp32", 3e-4), ("fp16", 8e-2)):
+        det = HipDetector(path, device=0, precision=prec, max_batch=2, max_imgsz=256)
+        om = Y.OracleYOLO(wd, names, sc)
+        imgs = [_tile("big512", 192, 256), _tile("big512", 192, 256)[:, ::-1].copy()]
+        xs = torch.cat([Y.preprocess(im, 256)[0] for im in imgs], 0)
+        with torch.no_grad():
+            raw = om.net.forward(xs).permute(0, 2, 1).contiguous()
+        pred = det.forward(netin_from_chw(xs, det.dtype))
+        torch.cuda.synchronize()
+        err = float((pred.cpu() - raw).abs().max())
+        assert err <= tol * max(1.0, float(raw.abs().max())), (scale, prec, err)
+        det.close()
