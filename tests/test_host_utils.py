@@ -1,0 +1,71 @@
+"""Host-side pieces that need no GPU: FITS ingest, the CLI's stage lowering, the tile partition."""
+import os
+import numpy as np
+import pytest
+from caesar_yolo_amd import utils, lib as L
+from caesar_yolo_amd import preprocessing as PP
+from caesar_yolo_amd.inference import partition_tiles
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_fits_reader_on_reference_fixture(golden_dir):
+    data, hdr = utils.read_fits_image(os.path.join(golden_dir, "galaxy0001.fits"))
+    ref = np.load(os.path.join(golden_dir, "preproc.npz"))["in/galaxy"]
+    assert data.shape == (132, 132) and data.dtype == np.dtype(">f4")
+    assert np.array_equal(np.asarray(data, np.float32), ref)
+    assert hdr["NAXIS1"] == 132 and hdr["BITPIX"] == -32 and abs(hdr["BMAJ"] - 0.002611826449586) < 1e-15
+    assert utils.image_id_of("/a/b/galaxy0001.fits") == "galaxy0001"
+
+
+def test_fits_roundtrip_and_degenerate_axes(tmp_path):
+    img = np.random.default_rng(0).normal(size=(37, 53)).astype(np.float32)
+    img[3, 4] = np.nan
+    p = str(tmp_path / "a.fits")
+    utils.write_fits_image(p, img, [("BMAJ", 0.01), ("BUNIT", "Jy/beam")])
+    data, hdr = utils.read_fits_image(p)
+    assert np.array_equal(np.asarray(data, np.float32), img, equal_nan=True) and hdr["BUNIT"] == "Jy/beam"
+    # 4-D cube with two degenerate leading axes: plane [0,0] is the image (utils.py:207-210 of the reference)
+    raw = open(p, "rb").read()
+    hdr_txt = raw[:2880].decode()
+    hdr_txt = hdr_txt.replace("NAXIS   =                    2", "NAXIS   =                    4")
+    cards = [hdr_txt[i:i + 80] for i in range(0, 2880, 80)]
+    end = next(i for i, c in enumerate(cards) if c.startswith("END"))
+    cards[end:end] = [("%-8s= %20d" % ("NAXIS3", 1)).ljust(80), ("%-8s= %20d" % ("NAXIS4", 1)).ljust(80)]
+    q = str(tmp_path / "b.fits")
+    open(q, "wb").write("".join(cards)[:2880].encode() + raw[2880:])
+    data4, hdr4 = utils.read_fits_image(q)
+    assert hdr4["NAXIS"] == 4 and np.array_equal(np.asarray(data4, np.float32), img, equal_nan=True)
+    assert utils.read_fits_image(str(tmp_path / "missing.fits")) is None
+
+
+def test_stage_lowering_matches_cli_order():
+    dp = PP.DataPreprocessor([PP.BkgSubtractor(sigma=3), PP.SigmaClipShifter(sigma=1), PP.SigmaClipper(10, 10),
+                              PP.ZScaleTransformer([0.25] * 3), PP.MinMaxNormalizer(0, 255)])
+    cfg = dp.program()
+    assert cfg.nprog == 1 and cfg.prog[0].n == 5
+    assert [cfg.prog[0].st[i].op for i in range(5)] == [L.OP_BKG, L.OP_SHIFT, L.OP_CLIP, L.OP_ZSCALE, L.OP_MINMAX]
+    c3 = PP.DataPreprocessor([PP.ChanResizer(3), PP.Chan3Trasformer(0, 10, 10, 0.25), PP.MinMaxNormalizer(0, 255)]).program()
+    assert c3.nprog == 3 and [c3.prog[i].n for i in range(3)] == [3, 3, 2]
+    assert [c3.prog[2].st[i].op for i in range(2)] == [L.OP_HISTEQ, L.OP_MINMAX]
+    assert PP.DataPreprocessor([]).program().nprog == 0
+    with pytest.raises(NotImplementedError):
+        PP.SigmaClipper(10, 10, chid=1)
+    with pytest.raises(RuntimeError):
+        dp(np.zeros((4, 4, 3)))                   # there is no CPU preprocessing path in the product
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
+def test_partition_is_balanced_and_complete(world):
+    grid = utils.generate_tiles(0, 16383, 0, 16383, 512, 512, 0.8, 0.8)
+    parts = partition_tiles(grid, 512, world)
+    assert sorted(t for p in parts for _, tids in p for t in tids) == list(range(len(grid)))
+    cost = []
+    for p in parts:
+        c = 0
+        for (th, tw), tids in p:
+            lb = L.letterbox(th, tw, 512)
+            c += lb.H * lb.W * len(tids)
+        cost.append(c)
+    assert max(cost) - min(cost) <= 2 * 512 * 512          # within two full tiles of each other
+    assert all(len(p) <= 4 for p in parts)
