@@ -31,7 +31,11 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 #define CY_OOB 0xFFFFFF00u
 
-// developer diagnostics (CY_DBG bit 6): per-segment s_memtime sums of the halo kernel's tap loop, summed over waves
+// developer diagnostics: per-segment s_memtime sums of the 3x3 kernels' stage loop, summed over waves.  Compiled in only
+// with -DCY_STAMPS_ENABLED=1 (then enabled at run time by CY_DBG bit 6); a stamped build is for SHARES, not for timing.
+#ifndef CY_STAMPS_ENABLED
+#define CY_STAMPS_ENABLED 0
+#endif
 __device__ unsigned long long g_stamps[8];
 __device__ __forceinline__ unsigned long long stamp_now() {
     unsigned long long t;
@@ -391,7 +395,7 @@ __global__ __launch_bounds__(WM * 128) void conv3x3_halo_kernel(const ConvArgs a
     if (DIST > 1 && total > 1) { w_issue(1); CY_WAIT_VM((DIST - 1) * WROUNDS); } else { CY_WAIT_VM(0); }
     __builtin_amdgcn_s_barrier();
     int it = 0;
-    const bool stamps = (a.dbg & 64) != 0;
+    const bool stamps = CY_STAMPS_ENABLED && (a.dbg & 64) != 0;
     unsigned long long acc_dma = 0, acc_cmp = 0, acc_wait = 0, acc_bar = 0;
     const unsigned long long t_begin = stamps ? stamp_now() : 0;
     for (int ch = 0; ch < chunks; ++ch) {
@@ -943,6 +947,10 @@ __global__ __launch_bounds__(512) void conv3x3_halo2_kernel(const ConvArgs a) {
     dma_slab(0, 1, 0, 1);
     __syncthreads();
     int g = 0;                                               // global stage counter: weight stage buffer = g & 1
+    const bool stamps = CY_STAMPS_ENABLED && (a.dbg & 64) != 0;
+    unsigned long long acc_dma = 0, acc_cmp = 0, acc_wait = 0, acc_bar = 0;
+    const unsigned long long t_begin = stamps ? stamp_now() : 0;
+    unsigned long long t0s = t_begin;
 #pragma unroll 1
     for (int cp = 0; cp < pairs; ++cp) {
 #pragma unroll
@@ -958,15 +966,35 @@ __global__ __launch_bounds__(512) void conv3x3_halo2_kernel(const ConvArgs a) {
             }
             if (st == 0) dma_patch(1, 2 * cp + 1);                                  // odd slab of this pair (needed from stage 4)
             if (st == 5 && cp + 1 < pairs) dma_patch(0, 2 * cp + 2);                // even slab of the next pair
+            unsigned long long t1 = 0, t2 = 0, t3 = 0;
+            if (stamps) { __builtin_amdgcn_sched_barrier(0); t1 = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int u = 2 * st + t, tap = u % 9;
                 compute(Pbuf + (u / 9) * P_BYTES, Wbuf + (g & 1) * W_BYTES + t * SLAB, tap / 3, tap % 3);
             }
+            if (stamps) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0); t2 = stamp_now(); __builtin_amdgcn_sched_barrier(0);
+                CY_WAIT_VM(0);
+                __builtin_amdgcn_sched_barrier(0); t3 = stamp_now(); __builtin_amdgcn_sched_barrier(0);
+            }
             __syncthreads();
+            if (stamps) {
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned long long t4 = stamp_now();
+                acc_dma += t1 - t0s; acc_cmp += t2 - t1; acc_wait += t3 - t2; acc_bar += t4 - t3;
+                t0s = t4;
+            }
         }
     }
 
+    if (stamps && lane == 0) {
+        const unsigned long long t_end = stamp_now();
+        atomicAdd(&g_stamps[0], acc_dma); atomicAdd(&g_stamps[1], acc_cmp); atomicAdd(&g_stamps[2], acc_wait);
+        atomicAdd(&g_stamps[3], acc_bar); atomicAdd(&g_stamps[4], t_end - t_begin); atomicAdd(&g_stamps[5], (unsigned long long)(pairs * 9));
+        atomicAdd(&g_stamps[6], 1ull);
+    }
     const int cbase = n0 + wn * 64 + fq * 16;
     float bv[16];
 #pragma unroll
