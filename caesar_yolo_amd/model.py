@@ -260,3 +260,26 @@ class YOLO(object):
         d, _, cnt = det.decode_nms(pred, lb.H, lb.W, img.shape[0], img.shape[1], float(conf), float(iou))
         n = int(cnt[0].item())
         return [Results(d[0, :n])]
+
+    def predict_tiles(self, device_mosaic, tile_coords, pre_cfg, device=None, imgsz=640, conf=0.25, iou=0.7,
+                      merge_overlap_iou_thr_soft=0.3, merge_overlap_iou_thr_hard=0.8, **ignored):
+        """Batched entry of the tile queue (SURVEY §8b "additive" entry; no counterpart in ultralytics).
+
+        device_mosaic : [ny,nx] fp32 tensor on the GPU (HipDetector.mosaic_to_device)
+        tile_coords   : B rows (xmin, xmax_excl, ymin, ymax_excl) like utils.generate_tiles, all of ONE shape
+        pre_cfg       : cy_preproc_cfg (DataPreprocessor.program())
+        Runs TileTask.find_sources' per-tile chain (caesar_yolo/inference.py:173-275: crop, preprocessing, model call,
+        process_detections) for the whole batch; returns one Results per tile (boxes in TILE pixel coordinates), or None
+        where the reference would skip the tile (pipeline gave None / constant rows)."""
+        det = self.engine(device)
+        tc = np.asarray(tile_coords, dtype=np.int64).reshape(-1, 4)
+        if len(tc) == 0:
+            return []
+        tw, th = tc[:, 1] - tc[:, 0], tc[:, 3] - tc[:, 2]
+        if (tw != tw[0]).any() or (th != th[0]).any():
+            raise ValueError("predict_tiles needs tiles of one shape per call (group ragged edge tiles separately)")
+        d, cnt, status = det.detect_tiles(device_mosaic, [(int(r[0]), int(r[2])) for r in tc], int(th[0]), int(tw[0]),
+                                          int(imgsz), pre_cfg, float(conf), float(iou),
+                                          float(merge_overlap_iou_thr_soft), float(merge_overlap_iou_thr_hard))
+        cnt, status = cnt.cpu().numpy(), status.cpu().numpy()
+        return [Results(d[b, :int(cnt[b])]) if status[b] == 0 else None for b in range(len(tc))]

@@ -114,3 +114,34 @@ def test_tiled_catalog_matches_oracle(tmp_path, monkeypatch):
     ref = R.merge_edge_sources(tile_sources)
     n1 = _compare_sources(got, ref)
     assert n1 <= max(2, len(ref) // 25), "%d catalog coordinates differ by one" % n1
+
+
+def test_predict_tiles_batched_entry():
+    """YOLO.predict_tiles (SURVEY §8b additive entry): per-tile Results equal the oracle's process_detections output, and
+    a tile whose pipeline gives None (all-zero after ingest) comes back as None."""
+    from caesar_yolo_amd.model import YOLO
+    from caesar_yolo_amd import preprocessing as PP
+    img = np.load(os.path.join(ROOT, "tests/golden/mosaic_c.npz"))["img"].astype(np.float32)
+    img[0:256, 512:768] = 0.0
+    model = YOLO(seeded_weights()[0], precision="fp32", max_batch=8, max_imgsz=256, device=0)
+    eng = model.engine()
+    mosaic = eng.mosaic_to_device(img)
+    cfg = PP.DataPreprocessor([PP.ZScaleTransformer([0.25] * 3), PP.MinMaxNormalizer(0, 255)]).program()
+    coords = [(0, 256, 0, 256), (256, 512, 0, 256), (512, 768, 0, 256), (128, 384, 128, 384), (600, 856, 400, 656)]
+    res = model.predict_tiles(mosaic, coords, cfg, imgsz=256, conf=CONF, iou=IOU,
+                              merge_overlap_iou_thr_soft=SOFT, merge_overlap_iou_thr_hard=HARD)
+    assert len(res) == len(coords) and res[2] is None
+    for (x0, x1, y0, y1), r in zip(coords, res):
+        ref = _oracle_tile(img[y0:y1, x0:x1], 256)
+        if ref is None:
+            assert r is None
+            continue
+        kb, ks, kc = ref
+        assert len(r.boxes.conf) == len(ks)
+        if len(ks):
+            np.testing.assert_allclose(r.boxes.conf.cpu().numpy(), ks, atol=1e-4)
+            np.testing.assert_array_equal(r.boxes.cls.cpu().numpy().astype(int), np.asarray(kc).astype(int))
+            np.testing.assert_allclose(r.boxes.xyxy.cpu().numpy(), kb, atol=256 * 1e-4)
+    with pytest.raises(ValueError):
+        model.predict_tiles(mosaic, [(0, 256, 0, 256), (0, 200, 0, 256)], cfg, imgsz=256)
+    assert model.predict_tiles(mosaic, [], cfg) == []
