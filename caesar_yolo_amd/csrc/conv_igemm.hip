@@ -19,6 +19,7 @@
 // halo kernels read at arbitrary row offsets; a 256-byte bank row holds two 128-byte tile rows).
 #include "cy_kernels.h"
 #include <cstdlib>
+#include <cstring>
 
 namespace cy {
 
@@ -30,6 +31,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 #define CY_OOB 0xFFFFFF00u
+#define CY_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
 // developer diagnostics: per-segment s_memtime sums of the 3x3 kernels' stage loop, summed over waves.  Compiled in only
 // with -DCY_STAMPS_ENABLED=1 (then enabled at run time by CY_DBG bit 6); a stamped build is for SHARES, not for timing.
@@ -61,12 +63,17 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
-template <typename T, int WM, int WN, int MI>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
-    constexpr int BM = WM * MI * 16, BN = WN * 64;
+// NSTAGE = 2: the slab for step s+1 is requested while step s computes and drained at the barrier (two workgroups of
+// four waves per CU hide each other's drains).  NSTAGE = 3 (the 256x128 tile, eight waves, one workgroup per CU): slabs
+// are requested TWO steps ahead and the wait before a barrier is a counted vmcnt that leaves the newest request in
+// flight, so an L2 round trip (about one step's worth of MFMA time for K-slabs of 64) is off the critical path.
+template <typename T, int WM, int WN, int MI, int NSTAGE = 2>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_igemm_kernel(const ConvArgs a) {
+    constexpr int BM = WM * MI * 16, BN = WN * 64, NT = WM * WN * 64, RPR = NT / 8;
     constexpr int BKE = Elem<T>::BKE, EPC = Elem<T>::EPC, ES = Elem<T>::ES;
-    constexpr int AROWS = BM / 32, BROWS = BN / 32;          // rows each thread stages per slab
+    constexpr int AROWS = BM / RPR, BROWS = BN / RPR;        // rows each thread stages per slab (RPR rows per round)
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int DIST = NSTAGE - 1, PER = AROWS + BROWS;    // slabs in flight; DMA instructions per slab per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -76,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     const int nwg = gridDim.x;
     const int id = xcd_remap(blockIdx.x, nwg);
     const int m0 = (id / ntn) * BM, n0 = (id % ntn) * BN;
-    const int taps = a.k * a.k;
+    const int taps = a.k * a.k, cpad = pad64(a.Cout);
     const int cchunks = (a.Cin + BKE - 1) / BKE;
     const int nslab = taps * cchunks;
 
@@ -93,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     const int HoWo = a.Ho * a.Wo;
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
-        const int m = m0 + r0 + 32 * i;
+        const int m = m0 + r0 + RPR * i;
         unsigned vm = 0;
         int p0 = 0, p1 = 0;
         if (m < M) {
@@ -133,16 +140,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
             if (!seg1) off = (unsigned)((pix0[i] + (a.up0 ? 0 : dpix)) * a.in0_ct + a.in0_coff + c) * ES;
             else       off = (unsigned)((pix1[i] + dpix) * a.in1_ct + a.in1_coff + (c - a.c0)) * ES;
             off = ok ? off : CY_OOB;
-            lds_void* dst = (lds_void*)(A + i * (32 * 128));
+            lds_void* dst = (lds_void*)(A + i * (RPR * 128));
             if (seg1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, dst, 16, off, 0, 0, 0);
             else      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, off, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < BROWS; ++i) {
-            const int n = n0 + r0 + 32 * i;
-            unsigned off = (unsigned)((n * taps + tap) * a.Cin + c) * ES;
-            off = cin_ok ? off : CY_OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)(Bm + i * (32 * 128)), 16, off, 0, 0, 0);
+            const int n = n0 + r0 + RPR * i;
+            const unsigned off = n < cpad ? (unsigned)(((cc * taps + tap) * cpad + n) * 128 + cq * 16) : CY_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)(Bm + i * (RPR * 128)), 16, off, 0, 0, 0);
         }
     };
 
@@ -202,16 +208,44 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
 
     // ---- main loop: the DMA for slab s+1 is in flight while slab s is on the matrix pipe; one barrier per slab
     // (__syncthreads drains vmcnt, which is what orders the landed DMA before the next slab's ds_reads)
-    int tap = 0, cc = 0;
-    dma(0, 0, 0);
-    __syncthreads();
-    for (int s = 0; s < nslab; ++s) {
-        int ntap = tap, ncc = cc + 1;
-        if (ncc == cchunks) { ncc = 0; ++ntap; }
-        if ((s + 1) < nslab) dma((s + 1) & 1, ntap, ncc);
-        compute(s & 1);
+    if constexpr (NSTAGE == 2) {
+        int tap = 0, cc = 0;
+        dma(0, 0, 0);
         __syncthreads();
-        tap = ntap; cc = ncc;
+        for (int s = 0; s < nslab; ++s) {
+            int ntap = tap, ncc = cc + 1;
+            if (ncc == cchunks) { ncc = 0; ++ntap; }
+            if ((s + 1) < nslab) dma((s + 1) & 1, ntap, ncc);
+            compute(s & 1);
+            __syncthreads();
+            tap = ntap; cc = ncc;
+        }
+    } else {
+        // ring of NSTAGE slabs, requests DIST steps ahead.  Slot (s+DIST) % NSTAGE last held slab s-1, whose readers are
+        // all past the barrier that ended step s-1 when step s issues into it.
+        int itap = 0, icc = 0, islot = 0;                    // issue cursor
+        auto issue = [&]() {
+            dma(islot, itap, icc);
+            if (++icc == cchunks) { icc = 0; ++itap; }
+            if (++islot == NSTAGE) islot = 0;
+        };
+#pragma unroll
+        for (int d = 0; d < DIST; ++d)
+            if (d < nslab) issue();
+        if (nslab >= DIST) { CY_WAIT_VM((DIST - 1) * PER); } else { CY_WAIT_VM(0); }
+        __builtin_amdgcn_s_barrier();
+        int slot = 0;
+        for (int s = 0; s < nslab; ++s) {
+            const bool more = s + DIST < nslab;
+            if (more) issue();
+            compute(slot);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // fragment reads of this slot are done (WAR on the ring)
+            if (more) { CY_WAIT_VM((DIST - 1) * PER); } else { CY_WAIT_VM(0); }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (++slot == NSTAGE) slot = 0;
+        }
     }
 
     // ---- epilogue: bias + SiLU (+ residual) and 16 contiguous channels per lane per pixel
@@ -286,7 +320,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
 // lane is a pixel, so a tap is just a row offset in the LDS image), while only the 128 x 64 weight slab changes per tap.
 // L2->LDS traffic per flop drops ~3x (TH=16: 185 KB per 37.7 MFLOP = 204 flop/B).  Zero padding of the halo and of
 // ragged image edges comes from the buffer range check, as in the generic kernel.
-#define CY_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
 template <int WM, int RING, int PB = 2>
 __global__ __launch_bounds__(WM * 128) void conv3x3_halo_kernel(const ConvArgs a) {
@@ -307,7 +340,8 @@ __global__ __launch_bounds__(WM * 128) void conv3x3_halo_kernel(const ConvArgs a
     const int wm = wave >> 1, wn = wave & 1;
     const int H = a.Hi, W = a.Wi;
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
-    const int ntn = (pad64(a.Cout) + BN - 1) / BN;
+    const int cpad = pad64(a.Cout);
+    const int ntn = (cpad + BN - 1) / BN;
     const int id = xcd_remap(blockIdx.x, gridDim.x);
     const int nt = id % ntn;
     int rest = id / ntn;
@@ -337,7 +371,7 @@ __global__ __launch_bounds__(WM * 128) void conv3x3_halo_kernel(const ConvArgs a
     for (int j = 0; j < WROUNDS; ++j) {
         const int row = (j * NW + wave) * 8 + (lane >> 3);
         const int q = (lane & 7) ^ (row & 7);
-        woff[j] = (unsigned)((n0 + row) * 9 * a.Cin + q * 8) * 2u;
+        woff[j] = n0 + row < cpad ? (unsigned)((n0 + row) * 128 + q * 16) : CY_OOB;
     }
     auto dma_patch = [&](int buf, int ch) {
 #pragma unroll
@@ -350,7 +384,7 @@ __global__ __launch_bounds__(WM * 128) void conv3x3_halo_kernel(const ConvArgs a
     auto dma_w = [&](int buf, int ch, int tap) {
 #pragma unroll
         for (int j = 0; j < WROUNDS; ++j) {
-            const unsigned off = woff[j] + (unsigned)((tap * a.Cin + ch * 64) * 2);
+            const unsigned off = woff[j] == CY_OOB ? CY_OOB : woff[j] + (unsigned)((ch * 9 + tap) * cpad * 128);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)(Wbuf + buf * W_BYTES + (j * NW + wave) * 1024), 16, off, 0, 0, 0);
         }
     };
@@ -512,7 +546,8 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(const ConvArgs a) {
     const int wm = wave >> 1, wn = wave & 1;
     const int H = a.Hi, W = a.Wi;
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
-    const int ntn = (pad64(a.Cout) + BN - 1) / BN;
+    const int cpad = pad64(a.Cout);
+    const int ntn = (cpad + BN - 1) / BN;
     const int id = xcd_remap(blockIdx.x, gridDim.x);
     const int nt = id % ntn;
     int rest = id / ntn;
@@ -540,7 +575,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(const ConvArgs a) {
     for (int j = 0; j < WROUNDS; ++j) {
         const int row = ((j * NW + wave) % WPIECES) * 8 + (lane >> 3);
         const int q = (lane & 7) ^ (row & 7);
-        woff[j] = (unsigned)((n0 + row) * 9 * a.Cin + q * 8) * 2u;
+        woff[j] = n0 + row < cpad ? (unsigned)((n0 + row) * 128 + q * 16) : CY_OOB;
     }
     auto dma_patch = [&](int buf, int ch) {
 #pragma unroll
@@ -555,7 +590,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(const ConvArgs a) {
         const int ch = n / 9, tap = n - ch * 9;
 #pragma unroll
         for (int j = 0; j < WROUNDS; ++j) {
-            const unsigned off = woff[j] + (unsigned)((tap * a.Cin + ch * 64) * 2);
+            const unsigned off = woff[j] == CY_OOB ? CY_OOB : woff[j] + (unsigned)((ch * 9 + tap) * cpad * 128);
             char* dst = Wbuf + (n % RING) * W_BYTES + ((j * NW + wave) % WPIECES) * 1024;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)dst, 16, off, 0, 0, 0);
         }
@@ -728,7 +763,7 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const ConvArgs a) {
             const int pc = j * NW + wave;                   // 72 pieces of 8 rows: piece = tap*8 + row block
             const int tap = pc >> 3, row = (pc & 7) * 8 + (lane >> 3);
             const int q = (lane & 7) ^ (row & 7);
-            const unsigned off = (unsigned)((row * 9 + tap) * 64 + q * 8) * 2u;
+            const unsigned off = (unsigned)((tap * 64 + row) * 128 + q * 16);         // slab-major packing, Cout_pad = 64, one K chunk
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)(Wl + pc * 1024), 16, off, 0, 0, 0);
         }
     }
@@ -870,7 +905,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo2_kernel(const ConvArgs a) {
     const int wm = wave >> 1, wn = wave & 1;
     const int H = a.Hi, W = a.Wi;
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
-    const int ntn = (pad64(a.Cout) + BN - 1) / BN;
+    const int cpad = pad64(a.Cout);
+    const int ntn = (cpad + BN - 1) / BN;
     const int id = xcd_remap(blockIdx.x, gridDim.x);
     const int nt = id % ntn;
     int rest = id / ntn;
@@ -896,7 +932,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo2_kernel(const ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int row = (j * NW + wave) * 8 + (lane >> 3);
-        woff[j] = (unsigned)((n0 + row) * 9 * a.Cin + ((lane & 7) ^ (row & 7)) * 8) * 2u;
+        woff[j] = n0 + row < cpad ? (unsigned)((n0 + row) * 128 + ((lane & 7) ^ (row & 7)) * 16) : CY_OOB;
     }
     auto dma_patch = [&](int buf, int ch) {
 #pragma unroll
@@ -908,7 +944,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo2_kernel(const ConvArgs a) {
     auto dma_slab = [&](int buf, int t, int ch, int tap) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const unsigned off = woff[j] + (unsigned)((tap * a.Cin + ch * 64) * 2);
+            const unsigned off = woff[j] == CY_OOB ? CY_OOB : woff[j] + (unsigned)((ch * 9 + tap) * cpad * 128);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)(Wbuf + buf * W_BYTES + t * SLAB + (j * NW + wave) * 1024), 16, off, 0, 0, 0);
         }
     };
@@ -1067,19 +1103,19 @@ static hipError_t launch_halo(const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <typename T, int WM, int WN, int MI>
+template <typename T, int WM, int WN, int MI, int NSTAGE = 2>
 static hipError_t launch_t(const ConvArgs& a, hipStream_t s) {
     constexpr int BM = WM * MI * 16, BN = WN * 64;
     const int M = a.B * a.Ho * a.Wo;
     const int ntm = (M + BM - 1) / BM, ntn = (pad64(a.Cout) + BN - 1) / BN;
-    const size_t lds = 2 * (BM + BN) * 128;
+    const size_t lds = NSTAGE * (BM + BN) * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, WM, WN, MI>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, WM, WN, MI, NSTAGE>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, MI>), dim3(ntm * ntn), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, MI, NSTAGE>), dim3(ntm * ntn), dim3(WM * WN * 64), lds, s, a);
     return hipGetLastError();
 }
 
@@ -1088,7 +1124,7 @@ static const char* const kVariantNames[CONV_NUM_VARIANTS] = {
     "conv_igemm_kernel<2,2,4> generic 128x128", "conv_igemm_kernel<4,1,2> generic 128x64",
     "conv3x3_halo2_kernel 3x3 s1 16x16px x128ch (halo<2,2> for odd slab counts)", "conv3x3_pp_kernel<2> 3x3 s1 16x16px x64ch",
     "conv3x3_pp_kernel<4> 3x3 s1 16x16px x128ch", "conv3x3_halo_kernel<4,*> 3x3 s1 16x16px x128ch",
-    "conv3x3_c64_kernel 3x3 s1 64->64 persistent"};
+    "conv3x3_c64_kernel 3x3 s1 64->64 persistent", "conv_igemm_kernel<4,2,4,3> generic 256x128, 3-slab ring"};
 const char* conv_variant_name(int v) { return v >= 0 && v < CONV_NUM_VARIANTS ? kVariantNames[v] : "?"; }
 
 int conv_variant(Precision p, const ConvArgs& a) {
@@ -1105,7 +1141,12 @@ int conv_variant(Precision p, const ConvArgs& a) {
         if (force == 4 || force == 43) return CONV_HALO16_128;
         return CONV_HALO8_128;
     }
-    return narrow ? CONV_GENERIC_64 : CONV_GENERIC_128;
+    if (narrow) return CONV_GENERIC_64;
+    // 1x1 and strided convs with enough 256-pixel tiles to fill the chip: deeper-pipelined 256x128 tile
+    static const int big = getenv("CY_BIG") ? atoi(getenv("CY_BIG")) : 1;
+    const long M = (long)a.B * a.Ho * a.Wo;
+    if (p == PREC_F16 && big && (M / 256) * ((pad64(a.Cout) + 127) / 128) >= big * 256) return CONV_GENERIC_BIG;
+    return CONV_GENERIC_128;
 }
 
 hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s) {
@@ -1120,6 +1161,7 @@ hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s) {
             if (v == 2 && (a.Cin / 64) % 2 == 0) return launch_halo2(b2, s);
             return v == 1 ? launch_halo<2, 3, 1>(b2, s) : launch_halo<2, 2>(b2, s);
         }
+        case CONV_GENERIC_BIG: return launch_t<f16, 4, 2, 4, 3>(a, s);
         case CONV_GENERIC_64: return p == PREC_F16 ? launch_t<f16, 4, 1, 2>(a, s) : launch_t<float, 4, 1, 2>(a, s);
         default: return p == PREC_F16 ? launch_t<f16, 2, 2, 4>(a, s) : launch_t<float, 2, 2, 4>(a, s);
     }
@@ -1132,23 +1174,31 @@ void debug_read_stamps(unsigned long long* out8, bool reset) {
 }
 
 // ------------------------------------------------------------------------------------------------ weights
+// Packed layout ("slab-major"): [K chunk of 128 B][tap][row in Cout_pad64][128 B].  The unit every kernel stages -- the
+// rows n0..n0+BN of one (chunk, tap) -- is ONE contiguous run of BN*128 bytes, so a DMA wave-instruction (8 rows) reads
+// 1 KiB of consecutive cache lines instead of 8 lines a whole filter row (k*k*Cin elements) apart.  K is zero-padded to
+// a whole chunk; rows are permuted per 64 so that a lane of the MFMA result holds 16 contiguous output channels.
 size_t packed_weight_bytes(Precision p, int cout, int cin, int k) {
-    return (size_t)pad64(cout) * k * k * cin * (p == PREC_F16 ? 2 : 4);
+    const int epb = p == PREC_F16 ? 64 : 32;
+    return (size_t)((cin + epb - 1) / epb) * k * k * pad64(cout) * 128;
 }
 
 void pack_weights(Precision p, const float* W, int cout, int cin, int k, void* dst) {
-    const int taps = k * k, cp = pad64(cout);
+    const int taps = k * k, cp = pad64(cout), epb = p == PREC_F16 ? 64 : 32, chunks = (cin + epb - 1) / epb;
+    memset(dst, 0, packed_weight_bytes(p, cout, cin, k));
     for (int row = 0; row < cp; ++row) {
         const int blk = row >> 6, ni = (row >> 4) & 3, rr = row & 15;
         const int n = blk * 64 + (rr >> 2) * 16 + ni * 4 + (rr & 3);      // channel held by packed row `row`
+        if (n >= cout) continue;
         for (int t = 0; t < taps; ++t)
             for (int c = 0; c < cin; ++c) {
-                const float v = n < cout ? W[((size_t)n * cin + c) * taps + t] : 0.0f;
-                const size_t o = ((size_t)row * taps + t) * cin + c;
+                const float v = W[((size_t)n * cin + c) * taps + t];
+                const size_t o = (((size_t)(c / epb) * taps + t) * cp + row) * epb + (c % epb);
                 if (p == PREC_F16) reinterpret_cast<f16*>(dst)[o] = (f16)v;
                 else reinterpret_cast<float*>(dst)[o] = v;
             }
     }
+    (void)chunks;
 }
 
 // ------------------------------------------------------------------------------------------------ stem

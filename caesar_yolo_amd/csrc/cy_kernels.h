@@ -15,7 +15,7 @@ enum Precision { PREC_F16 = 0, PREC_F32 = 1 };
 struct ConvArgs {
     const void* in0; int in0_ct, in0_coff, c0, up0;   // segment 0: base, channels per pixel of the buffer, channel offset, #channels
     const void* in1; int in1_ct, in1_coff, c1;        // segment 1 (c1 == 0: absent)
-    const void* wgt;                                   // packed [Cout_pad64][k*k][Cin]; rows permuted per 64 (pack_weights)
+    const void* wgt;                                   // packed [K chunk][k*k][Cout_pad64][128 B]; rows permuted per 64 (pack_weights)
     const float* bias;                                 // [Cout_pad64]
     void* out; int out_ct, out_coff;                   // NHWC destination slice
     int out_bs, out_ro;                                // destination pixel = b*out_bs + out_ro + (ho*Wo+wo)
@@ -38,7 +38,7 @@ struct PoolArgs {   // MaxPool2d(5,1,2) on a channel slice of an NHWC buffer, -i
 };
 
 hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s);
-enum ConvVariant { CONV_GENERIC_128 = 0, CONV_GENERIC_64, CONV_HALO8_128, CONV_PP_64, CONV_PP_128, CONV_HALO16_128, CONV_C64_PERSIST, CONV_NUM_VARIANTS };
+enum ConvVariant { CONV_GENERIC_128 = 0, CONV_GENERIC_64, CONV_HALO8_128, CONV_PP_64, CONV_PP_128, CONV_HALO16_128, CONV_C64_PERSIST, CONV_GENERIC_BIG, CONV_NUM_VARIANTS };
 int conv_variant(Precision p, const ConvArgs& a);          // which kernel launch_conv picks
 const char* conv_variant_name(int v);
 void debug_read_stamps(unsigned long long* out8, bool reset);   // developer diagnostics (CY_DBG=64)

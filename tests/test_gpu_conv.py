@@ -27,6 +27,10 @@ CASES = [  # B, H, W, Cin, Cout, k, s, act, residual
     (5, 40, 48, 64, 64, 3, 1, True, True),        # ping-pong kernel, 64-channel tiles, residual
     (2, 24, 24, 256, 64, 3, 1, True, False),      # ping-pong kernel, 4 input slabs
     (1, 16, 16, 128, 40, 3, 1, True, False),      # ping-pong kernel, ragged Cout
+    (4, 128, 128, 128, 256, 1, 1, True, False),   # 256x128 three-slab ring kernel (fp16 context), 1x1
+    (3, 120, 100, 192, 160, 1, 1, True, True),    # ring kernel: ragged pixel tail (M % 256 != 0), ragged Cout, residual
+    (2, 256, 256, 64, 256, 3, 2, True, False),    # ring kernel: 3x3 stride 2 (im2col gather with padding masks)
+    (16, 64, 64, 64, 128, 1, 1, False, False),    # ring kernel: a single K-slab (prologue shorter than the ring)
 ]
 
 
