@@ -30,7 +30,7 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(mosaic_host, grid, names_w, budget_s=20.0, max_tiles=24):
+def cpu_baseline(mosaic_host, grid, names_w, budget_s=22.0, max_tiles=32, budget_8t_s=8.0):
     """The CPU oracle (restated reference path: numpy preprocessing + torch-CPU fp32 YOLOv8l + NMS + IoU merge),
     sequential, batch 1 like caesar_yolo/inference.py:611-622, on a bounded sample of the same tiles."""
     import numpy as np
@@ -44,22 +44,33 @@ def cpu_baseline(mosaic_host, grid, names_w, budget_s=20.0, max_tiles=24):
     dp = P.build_pipeline([("zscale", dict(contrasts=[0.25] * 3)), ("minmax", dict(norm_min=0, norm_max=255))])
     full = [i for i, t in enumerate(grid) if t[1] - t[0] == 512 and t[3] - t[2] == 512]
     sample = full[len(full) // 3:][:max_tiles]
-    done, t0 = 0, time.time()
-    for tid in sample:
-        x0, x1, y0, y1 = grid[tid]
-        tile = np.array(mosaic_host[y0:y1, x0:x1], dtype=np.float32)
-        tile[~np.isfinite(tile)] = 0
-        img = dp(P.to_cube(tile))
-        if img is not None and not P.rows_constant(img):
-            det, _, _, _ = om.predict_raw(img, 512, 0.7, 0.5)
-            R.process_detections(det[:, :4].numpy(), det[:, 4].numpy(), det[:, 5].numpy(), 0.7, 0.3, 0.8)
-        done += 1
-        if time.time() - t0 > budget_s:
-            break
-    dt = time.time() - t0
-    return {"value": done / dt, "unit": "tiles/s", "cores": cores, "kind": "port",
-            "sample": "%d full 512x512 tiles of the S16k grid (tids %d..), sequential batch 1, zscale+minmax + torch-CPU "
-                      "fp32 yolov8l + NMS + IoU merge, %.1f s" % (done, sample[0], dt)}
+
+    def run(tids, budget):
+        done, t0 = 0, time.time()
+        for tid in tids:
+            x0, x1, y0, y1 = grid[tid]
+            tile = np.array(mosaic_host[y0:y1, x0:x1], dtype=np.float32)
+            tile[~np.isfinite(tile)] = 0
+            img = dp(P.to_cube(tile))
+            if img is not None and not P.rows_constant(img):
+                det, _, _, _ = om.predict_raw(img, 512, 0.7, 0.5)
+                R.process_detections(det[:, :4].numpy(), det[:, 4].numpy(), det[:, 5].numpy(), 0.7, 0.3, 0.8)
+            done += 1
+            if time.time() - t0 > budget:
+                break
+        return done, time.time() - t0
+    run(sample[:1], 60.0)                                  # untimed first tile (thread pool / allocator warm-up)
+    done, dt = run(sample, budget_s)
+    out = {"value": done / dt, "unit": "tiles/s", "cores": cores, "kind": "port",
+           "sample": "%d full 512x512 tiles of the S16k grid (tids %d..), sequential batch 1, zscale+minmax + torch-CPU "
+                     "fp32 yolov8l + NMS + IoU merge, %.1f s" % (done, sample[0], dt)}
+    if cores > 8:                                          # also report the 8-thread figure
+        torch.set_num_threads(8)
+        d8, t8 = run(sample, budget_8t_s)
+        torch.set_num_threads(cores)
+        out["value_8_threads"] = d8 / t8
+        out["sample_8_threads"] = "%d tiles, %.1f s" % (d8, t8)
+    return out
 
 
 def pmc_traffic(kernel_label):
@@ -73,6 +84,8 @@ def pmc_traffic(kernel_label):
             if fam in n:
                 return fam
         if "conv_igemm_kernel" in n:
+            if "<4,2,4,3>" in n or "Li4ELi2ELi4ELi3E" in n:
+                return "conv_igemm_kernel<4,2,4,3>"
             return "conv_igemm_kernel<2,2,4>" if ("<2,2,4>" in n or "Li2ELi2ELi4E" in n) else "conv_igemm_kernel<4,1,2>"
         return None
     want, best = family(kernel_label), None

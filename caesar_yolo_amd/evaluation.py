@@ -29,6 +29,8 @@ class Analyzer(object):
         self.merge_overlap_iou_thr_hard = config['merge_overlap_iou_thr_hard']
         self.write_to_json = config.get('save_catalog', True)
         self.outfile_json = ""
+        self.write_to_ds9 = config.get('save_region', True)      # caesar_yolo/evaluation.py:97
+        self.outfile_ds9 = ""
         self.obj_name_tag = ""
         self.image_id = -1
         self.image_xmin = self.image_ymin = 0
@@ -75,7 +77,13 @@ class Analyzer(object):
                         "objs": objs_from_detections(dd, self.class_names, nx, ny, xmin, ymin, self.obj_name_tag)}
         if self.write_to_json:
             self.write_json_results(self.outfile_json or ('out_' + str(self.image_id) + '.json'))
+        if self.write_to_ds9:                                     # caesar_yolo/evaluation.py:228-234
+            self.write_ds9_regions(self.outfile_ds9 or ('out_' + str(self.image_id) + '.reg'))
         return 0
+
+    def write_ds9_regions(self, outfile):
+        from . import utils
+        utils.write_ds9_regions(outfile, self.results.get("objs", []), merged_tag=False)
 
     def write_json_results(self, outfile):
         if not self.results:

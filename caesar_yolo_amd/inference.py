@@ -239,6 +239,8 @@ class SFinder(object):
         self.nx = self.ny = -1
         self.outfile_json = config.get('outfile_json', '')
         self.write_to_json = config.get('save_catalog', True)
+        self.write_to_ds9 = config.get('save_region', True)      # caesar_yolo/inference.py:331
+        self.outfile_ds9 = ""
         self.runtime = 0.0
         self.stats = {}
 
@@ -297,6 +299,9 @@ class SFinder(object):
             out = self.outfile_json or ('out_' + str(self.image_id) + '.json')
             with open(out, 'w') as fp:
                 json.dump(self.results, fp, indent=2, sort_keys=True)
+        if self.write_to_ds9:                                     # caesar_yolo/evaluation.py:228-234
+            utils.write_ds9_regions(self.outfile_ds9 or ('out_' + str(self.image_id) + '.reg'), self.results["objs"],
+                                    merged_tag=False)
         return 0
 
     # ---- tiled (reference :578-658)
@@ -328,6 +333,8 @@ class SFinder(object):
                 out = self.outfile_json or ('catalog_' + str(self.image_id) + '.json')
                 with open(out, 'w') as fp:
                     json.dump(self.sources, fp, indent=2, sort_keys=True)
+            if self.write_to_ds9:                                 # caesar_yolo/inference.py:1188-1194
+                utils.write_ds9_regions(self.outfile_ds9 or ('ds9_' + str(self.image_id) + '.reg'), src)
         if world > 1:
             dist.barrier()
         self.runtime = time.time() - t0

@@ -136,5 +136,45 @@ def write_fits_image(filename, data, cards=None):
         fp.write(b"\0" * ((-len(payload)) % 2880))
 
 
+# --------------------------------------------------------------------------------------------- DS9 regions
+CLASS_COLOR_MAP_DS9 = {'bkg': "black", 'spurious': "red", 'compact': "blue", 'extended': "green",
+                       'extended-multisland': "yellow", 'flagged': "black", 'diffuse': "magenta"}
+# (caesar_yolo/inference.py:334-342, evaluation.py class_color_map_ds9)
+
+
+def ds9_region_lines(objs, color_map=None, merged_tag=True):
+    """One `box(...)` line per catalog object (caesar_yolo/inference.py:1214-1263, evaluation.py:487-528): centre
+    x1 + dx/2, y1 + dy/2 (0-based pixel, written 1-based as DS9 'image' coordinates), size dx x dy, text = source name,
+    tags = class name [+ BORDER if edge] [+ MERGED if merged], colour by class.
+    The reference serialises through the third-party `regions` package (absent here): this is the DS9 text format that
+    package emits (header, `image` frame, 1-based centres, fixed-point numbers); byte-compatibility is unpinned."""
+    cmap = color_map or CLASS_COLOR_MAP_DS9
+    lines = []
+    for o in objs:
+        dx, dy = o['x2'] - o['x1'], o['y2'] - o['y1']
+        xc, yc = o['x1'] + 0.5 * dx, o['y1'] + 0.5 * dy
+        tags = [o['class_name']]
+        if o.get('edge'):
+            tags.append('BORDER')
+        if merged_tag and o.get('merged'):
+            tags.append('MERGED')
+        meta = "text={%s} " % o['name'] + " ".join("tag={%s}" % t for t in tags)
+        lines.append("box(%.4f,%.4f,%.4f,%.4f,%.8f) # %s color=%s" % (xc + 1, yc + 1, dx, dy, 0.0, meta,
+                                                                       cmap.get(o['class_name'], "white")))
+    return lines
+
+
+def write_ds9_regions(filename, objs, color_map=None, merged_tag=True):
+    """-> number of regions written; nothing is written (and a warning logged) for an empty list, like the reference."""
+    if not objs:
+        logger.warning("Region list with detected objects is empty, nothing to be written...")
+        return 0
+    with open(filename, "w") as fp:
+        fp.write("# Region file format: DS9 astropy/regions\nimage\n")
+        for ln in ds9_region_lines(objs, color_map, merged_tag):
+            fp.write(ln + "\n")
+    return len(objs)
+
+
 def image_id_of(path):
     return os.path.splitext(os.path.basename(os.path.abspath(path)))[0]

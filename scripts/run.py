@@ -144,7 +144,7 @@ def main(argv=None):
               'devices': [str(x) for x in args.devices.split(',')], 'use_multi_gpu': args.multigpu, 'iou_thr': args.iouThr,
               'score_thr': args.scoreThr, 'merge_overlap_iou_thr_soft': args.merge_overlap_iou_thr_soft,
               'merge_overlap_iou_thr_hard': args.merge_overlap_iou_thr_hard, 'outfile': args.detect_outfile,
-              'outfile_json': args.detect_outfile_json, 'save_region': False, 'tile_batch': args.tile_batch,
+              'outfile_json': args.detect_outfile_json, 'save_region': True, 'tile_batch': args.tile_batch,
               'precision': args.precision})
     tile_max = max(args.tile_xsize, args.tile_ysize) if args.split_img_in_tiles else 0
     model = YOLO(args.weights, precision=args.precision, max_batch=args.tile_batch if args.split_img_in_tiles else 1,

@@ -69,3 +69,19 @@ def test_partition_is_balanced_and_complete(world):
         cost.append(c)
     assert max(cost) - min(cost) <= 2 * 512 * 512          # within two full tiles of each other
     assert all(len(p) <= 4 for p in parts)
+
+
+def test_ds9_region_writer(tmp_path):
+    """DS9 box regions from catalog objects (caesar_yolo/inference.py:1214-1263): centre/size arithmetic, 1-based image
+    coordinates, tags and class colours; an empty list writes nothing."""
+    from caesar_yolo_amd import utils
+    objs = [dict(name="S1", x1=10, x2=30, y1=5, y2=15, class_name="compact", edge=False, merged=False),
+            dict(name="S2_t3", x1=0, x2=7, y1=100, y2=103, class_name="extended", edge=True, merged=True)]
+    out = tmp_path / "r.reg"
+    assert utils.write_ds9_regions(str(out), objs) == 2
+    lines = out.read_text().splitlines()
+    assert lines[0].startswith("# Region file format: DS9") and lines[1] == "image"
+    assert lines[2] == "box(21.0000,11.0000,20.0000,10.0000,0.00000000) # text={S1} tag={compact} color=blue"
+    assert lines[3] == "box(4.5000,102.5000,7.0000,3.0000,0.00000000) # text={S2_t3} tag={extended} tag={BORDER} tag={MERGED} color=green"
+    assert utils.ds9_region_lines(objs[1:], merged_tag=False)[0].count("tag=") == 2      # Analyzer regions carry no MERGED tag
+    assert utils.write_ds9_regions(str(tmp_path / "e.reg"), []) == 0 and not (tmp_path / "e.reg").exists()
