@@ -210,7 +210,8 @@ class Results(object):
 class YOLO(object):
     """Drop-in for `ultralytics.YOLO(weights)` on the reference's detect path.
 
-    `weights` is a CYW1 file (caesar_yolo_amd.weights); the string "seeded:<scale>:<nc>[:seed]" builds the
+    `weights` is a CYW1 file (caesar_yolo_amd.weights) or an ultralytics YOLOv8 detection `.pt` checkpoint (read as
+    data by caesar_yolo_amd.pt_import: no ultralytics needed); the string "seeded:<scale>:<nc>[:seed]" builds the
     deterministic random-init checkpoint used by the tests and the benchmark (no trained weights ship with the
     reference)."""
 
@@ -240,7 +241,23 @@ class YOLO(object):
             return path
         if not os.path.isfile(weights):
             raise FileNotFoundError(weights)
-        return weights
+        with open(weights, "rb") as fp:
+            magic = fp.read(4)
+        if magic == b"CYW1":
+            return weights
+        # an ultralytics checkpoint (scripts/run.py:347 passes the .pt path): converted once, without unpickling any of
+        # its classes (pt_import), and cached next to the seeded files
+        import tempfile
+        from . import pt_import
+        st = os.stat(weights)
+        cache = os.environ.get("CAESAR_YOLO_CACHE", os.path.join(tempfile.gettempdir(), "caesar_yolo_amd_%d" % os.getuid()))
+        os.makedirs(cache, exist_ok=True)
+        path = os.path.join(cache, "%s_%d_%d.cyw" % (os.path.splitext(os.path.basename(weights))[0], st.st_size, int(st.st_mtime)))
+        if not os.path.exists(path):
+            tmp = path + ".%d.tmp" % os.getpid()
+            pt_import.convert_pt_to_cyw(weights, tmp)
+            os.replace(tmp, path)
+        return path
 
     def engine(self, device=None):
         if self._det is None:
