@@ -83,7 +83,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_ige
     const int nwg = gridDim.x;
     const int id = xcd_remap(blockIdx.x, nwg);
     const int m0 = (id / ntn) * BM, n0 = (id % ntn) * BN;
-    const int taps = a.k * a.k, cpad = pad64(a.Cout);
+    const int taps = a.k * a.k, cpad = pad128(a.Cout);
     const int cchunks = (a.Cin + BKE - 1) / BKE;
     const int nslab = taps * cchunks;
 
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_ige
 #pragma unroll
         for (int i = 0; i < BROWS; ++i) {
             const int n = n0 + r0 + RPR * i;
-            const unsigned off = n < cpad ? (unsigned)(((cc * taps + tap) * cpad + n) * 128 + cq * 16) : CY_OOB;
+            const unsigned off = (unsigned)(((cc * taps + tap) * cpad + n) * 128 + cq * 16);      // rows are padded to 128: always valid
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)(Bm + i * (RPR * 128)), 16, off, 0, 0, 0);
         }
     };
@@ -340,8 +340,8 @@ __global__ __launch_bounds__(WM * 128) void conv3x3_halo_kernel(const ConvArgs a
     const int wm = wave >> 1, wn = wave & 1;
     const int H = a.Hi, W = a.Wi;
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
-    const int cpad = pad64(a.Cout);
-    const int ntn = (cpad + BN - 1) / BN;
+    const int cpad = pad128(a.Cout);                      // packed weight rows (zero rows past Cout)
+    const int ntn = (pad64(a.Cout) + BN - 1) / BN;
     const int id = xcd_remap(blockIdx.x, gridDim.x);
     const int nt = id % ntn;
     int rest = id / ntn;
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(WM * 128) void conv3x3_halo_kernel(const ConvArgs a
     for (int j = 0; j < WROUNDS; ++j) {
         const int row = (j * NW + wave) * 8 + (lane >> 3);
         const int q = (lane & 7) ^ (row & 7);
-        woff[j] = n0 + row < cpad ? (unsigned)((n0 + row) * 128 + q * 16) : CY_OOB;
+        woff[j] = (unsigned)((n0 + row) * 128 + q * 16);
     }
     auto dma_patch = [&](int buf, int ch) {
 #pragma unroll
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(WM * 128) void conv3x3_halo_kernel(const ConvArgs a
     auto dma_w = [&](int buf, int ch, int tap) {
 #pragma unroll
         for (int j = 0; j < WROUNDS; ++j) {
-            const unsigned off = woff[j] == CY_OOB ? CY_OOB : woff[j] + (unsigned)((ch * 9 + tap) * cpad * 128);
+            const unsigned off = woff[j] + (unsigned)((ch * 9 + tap) * cpad * 128);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)(Wbuf + buf * W_BYTES + (j * NW + wave) * 1024), 16, off, 0, 0, 0);
         }
     };
@@ -546,8 +546,8 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(const ConvArgs a) {
     const int wm = wave >> 1, wn = wave & 1;
     const int H = a.Hi, W = a.Wi;
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
-    const int cpad = pad64(a.Cout);
-    const int ntn = (cpad + BN - 1) / BN;
+    const int cpad = pad128(a.Cout);                      // packed weight rows (zero rows past Cout)
+    const int ntn = (pad64(a.Cout) + BN - 1) / BN;
     const int id = xcd_remap(blockIdx.x, gridDim.x);
     const int nt = id % ntn;
     int rest = id / ntn;
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(const ConvArgs a) {
     for (int j = 0; j < WROUNDS; ++j) {
         const int row = ((j * NW + wave) % WPIECES) * 8 + (lane >> 3);
         const int q = (lane & 7) ^ (row & 7);
-        woff[j] = n0 + row < cpad ? (unsigned)((n0 + row) * 128 + q * 16) : CY_OOB;
+        woff[j] = (unsigned)((n0 + row) * 128 + q * 16);
     }
     auto dma_patch = [&](int buf, int ch) {
 #pragma unroll
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(const ConvArgs a) {
         const int ch = n / 9, tap = n - ch * 9;
 #pragma unroll
         for (int j = 0; j < WROUNDS; ++j) {
-            const unsigned off = woff[j] == CY_OOB ? CY_OOB : woff[j] + (unsigned)((ch * 9 + tap) * cpad * 128);
+            const unsigned off = woff[j] + (unsigned)((ch * 9 + tap) * cpad * 128);
             char* dst = Wbuf + (n % RING) * W_BYTES + ((j * NW + wave) % WPIECES) * 1024;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)dst, 16, off, 0, 0, 0);
         }
@@ -763,7 +763,7 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const ConvArgs a) {
             const int pc = j * NW + wave;                   // 72 pieces of 8 rows: piece = tap*8 + row block
             const int tap = pc >> 3, row = (pc & 7) * 8 + (lane >> 3);
             const int q = (lane & 7) ^ (row & 7);
-            const unsigned off = (unsigned)((tap * 64 + row) * 128 + q * 16);         // slab-major packing, Cout_pad = 64, one K chunk
+            const unsigned off = (unsigned)((tap * 128 + row) * 128 + q * 16);        // slab-major packing, rows padded to 128, one K chunk
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)(Wl + pc * 1024), 16, off, 0, 0, 0);
         }
     }
@@ -905,8 +905,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo2_kernel(const ConvArgs a) {
     const int wm = wave >> 1, wn = wave & 1;
     const int H = a.Hi, W = a.Wi;
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
-    const int cpad = pad64(a.Cout);
-    const int ntn = (cpad + BN - 1) / BN;
+    const int cpad = pad128(a.Cout);                      // packed weight rows (zero rows past Cout)
+    const int ntn = (pad64(a.Cout) + BN - 1) / BN;
     const int id = xcd_remap(blockIdx.x, gridDim.x);
     const int nt = id % ntn;
     int rest = id / ntn;
@@ -932,7 +932,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo2_kernel(const ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int row = (j * NW + wave) * 8 + (lane >> 3);
-        woff[j] = n0 + row < cpad ? (unsigned)((n0 + row) * 128 + ((lane & 7) ^ (row & 7)) * 16) : CY_OOB;
+        woff[j] = (unsigned)((n0 + row) * 128 + ((lane & 7) ^ (row & 7)) * 16);
     }
     auto dma_patch = [&](int buf, int ch) {
 #pragma unroll
@@ -944,7 +944,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo2_kernel(const ConvArgs a) {
     auto dma_slab = [&](int buf, int t, int ch, int tap) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const unsigned off = woff[j] == CY_OOB ? CY_OOB : woff[j] + (unsigned)((ch * 9 + tap) * cpad * 128);
+            const unsigned off = woff[j] + (unsigned)((ch * 9 + tap) * cpad * 128);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)(Wbuf + buf * W_BYTES + t * SLAB + (j * NW + wave) * 1024), 16, off, 0, 0, 0);
         }
     };
@@ -1088,6 +1088,215 @@ static hipError_t launch_halo2(const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ 3x3 s1, 512 px x 128 ch
+// The halo kernels above are not limited by matrix-pipe or LDS bandwidth but by the cost of getting bytes into LDS: every
+// 1 KiB LDS-DMA piece holds its issuing wave for 60-180 cycles (MI355X_MICROARCH.md, "LDS-DMA piece issue cost"), and
+// conv3x3_halo2_kernel needs 41 pieces per 64 MFMAs of every wave.  Weight bytes per flop only depend on the number of
+// PIXELS a workgroup owns, so this variant doubles them: a 16 x 32-pixel patch (512 px) x 128 channels, each wave a
+// 128 px x 64 ch tile (acc = 128 VGPRs).  To make that fit in LDS the K slab is 32 channels (LDS rows of 64 B):
+//   halo 18 x 34 px x 64 B = 38.3 KiB (x2 buffers), weight stage = two taps x 128 rows x 64 B = 16 KiB (x3 ring)  -> 128 KiB
+// One stage is again 64 MFMAs per wave but only ~25 DMA pieces and 24 instead of 32 fragment reads, and the ring is
+// deep enough to request weights two stages ahead (counted vmcnt; halo pieces stay in flight for 2-3 stages).
+// 64-byte rows: chunk' = chunk ^ 2*((row>>2)&1) is conflict-free for the ds_read_b128 lane groups at any row offset.
+// Weights come from the second packed copy with 64-byte K chunks (ConvArgs::wgt32).
+__global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
+    constexpr int TH = 16, TW = 32, NW = 8, BN = 128, PWID = TW + 2;
+    constexpr int PR = (TH + 2) * PWID, NPC = (PR + 15) / 16, PROUNDS = (NPC + NW - 1) / NW;
+    constexpr int P_BYTES = PROUNDS * NW * 1024, SLAB = BN * 64, W_BYTES = 2 * SLAB, RING = 3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const Pbuf = smem;
+    char* const Wbuf = smem + 2 * P_BYTES;
+    typedef __attribute__((address_space(3))) void lds_void;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int H = a.Hi, W = a.Wi;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int cpad = pad128(a.Cout);                      // packed weight rows (zero rows past Cout)
+    const int ntn = (pad64(a.Cout) + BN - 1) / BN;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = id % ntn;
+    int rest = id / ntn;
+    const int tx = rest % tiles_x; rest /= tiles_x;
+    const int ty = rest % tiles_y;
+    const int b = rest / tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW, n0 = nt * BN;
+    const int pairs = a.Cin / 64;                           // pairs of 32-channel slabs
+
+    const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in0), 0, a.in0_bytes, 0x00020000);
+    const auto rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wgt32), 0, a.wgt32_bytes, 0x00020000);
+    unsigned poff[PROUNDS];
+#pragma unroll
+    for (int j = 0; j < PROUNDS; ++j) {
+        const int r = (j * NW + wave) * 16 + (lane >> 2);
+        const int ry = r / PWID, rx = r - ry * PWID;
+        const int y = y0 + ry - 1, x = x0 + rx - 1;
+        const int q = (lane & 3) ^ (((r >> 2) & 1) << 1);
+        const bool ok = r < PR && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+        poff[j] = ok ? (unsigned)(((b * H + y) * W + x) * a.in0_ct + a.in0_coff + q * 8) * 2u : CY_OOB;
+    }
+    unsigned woff;
+    {
+        const int row = wave * 16 + (lane >> 2);
+        woff = (unsigned)((n0 + row) * 64 + ((lane & 3) ^ (((row >> 2) & 1) << 1)) * 16);
+    }
+    auto dma_patch = [&](int buf, int slab) {               // slab: 32-channel slab index
+#pragma unroll
+        for (int j = 0; j < PROUNDS; ++j) {
+            const unsigned off = poff[j] == CY_OOB ? CY_OOB : poff[j] + (unsigned)(slab * 64);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_void*)(Pbuf + buf * P_BYTES + (j * NW + wave) * 1024), 16, off, 0, 0, 0);
+        }
+    };
+    auto dma_stage = [&](int ring, int slab0, int u0) {     // taps u0, u0+1 of the pair starting at slab slab0 (u in 0..17)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int u = u0 + t, sl = slab0 + u / 9, tap = u % 9;
+            const unsigned off = woff + (unsigned)((sl * 9 + tap) * cpad * 64);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)(Wbuf + ring * W_BYTES + t * SLAB + wave * 1024), 16, off, 0, 0, 0);
+        }
+    };
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+    // Fragment addresses = per-lane base + compile-time offset.  A halo row is r = wm*4*PWID + base + fr with `base`
+    // known at compile time per (tap, mi) and wm*4*PWID = 0 mod 8, so the swizzle bit ((r>>2)&1) only depends on
+    // base & 7 and the lane: eight lane bases cover every tap.  Weight rows are 0 mod 16 + fr: one lane base.
+    unsigned pb[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        pb[c] = (unsigned)(wm * 4 * PWID * 64 + fr * 64 + ((fq ^ ((((c + fr) >> 2) & 1) << 1)) << 4));
+    const unsigned wl = (unsigned)(2 * P_BYTES + (wn * 64 + fr) * 64 + ((fq ^ (((fr >> 2) & 1) << 1)) << 4));
+    // One stage = two taps = four half-steps of 16 MFMAs (4 channel blocks x 4 pixel fragments).  The fragment reads of
+    // half-step h+1 are issued before the MFMAs of half-step h (register double buffer), and a scheduling fence after
+    // each half-step keeps the compiler from hoisting more than that (the kernel sits at the 256-VGPR limit: 128 acc).
+    f16x8 xa[2][4], wb[2][4];
+    auto load_x = [&](f16x8* dst, int pbuf_off, int kh, int kw, int half) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int mi = half * 4 + m;
+            const int base = ((mi >> 1) + kh) * PWID + (mi & 1) * 16 + kw;
+            dst[m] = *reinterpret_cast<const f16x8*>(smem + pb[base & 7] + (pbuf_off + base * 64));
+        }
+    };
+    auto load_w = [&](f16x8* dst, int wbuf_off) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) dst[ni] = *reinterpret_cast<const f16x8*>(smem + wl + (wbuf_off + ni * 1024));
+    };
+    auto mma = [&](const f16x8* w, const f16x8* x, int half) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                acc[ni][half * 4 + m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ni], x[m], acc[ni][half * 4 + m], 0, 0, 0);
+    };
+    auto stage_compute = [&](int st) {                       // taps u = 2*st, 2*st+1 of the current slab pair
+        const int u0 = 2 * st, u1 = u0 + 1, t0 = u0 % 9, t1 = u1 % 9;
+        const int p0 = (u0 / 9) * P_BYTES, p1 = (u1 / 9) * P_BYTES, w0 = (st % 3) * W_BYTES, w1 = w0 + SLAB;
+        load_w(wb[0], w0);
+        load_x(xa[0], p0, t0 / 3, t0 % 3, 0);
+        load_x(xa[1], p0, t0 / 3, t0 % 3, 1);
+        mma(wb[0], xa[0], 0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_w(wb[1], w1);
+        load_x(xa[0], p1, t1 / 3, t1 % 3, 0);
+        mma(wb[0], xa[1], 1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_x(xa[1], p1, t1 / 3, t1 % 3, 1);
+        mma(wb[1], xa[0], 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(wb[1], xa[1], 1);
+    };
+
+    // prologue: halo of slab 0, weight stages 0 and 1
+    dma_patch(0, 0);
+    dma_stage(0, 0, 0);
+    dma_stage(1, 0, 2);
+    CY_WAIT_VM(2);
+    __builtin_amdgcn_s_barrier();
+#pragma unroll 1
+    for (int cp = 0; cp < pairs; ++cp) {
+        const bool more = cp + 1 < pairs;
+#pragma unroll
+        for (int st = 0; st < 9; ++st) {
+            // stage g = 9*cp + st uses ring slot st % 3; request the weights of stage g+2 and the halo buffers just freed
+            const bool has_w = st <= 6 || more;
+            if (st <= 6) dma_stage((st + 2) % 3, 2 * cp, 2 * (st + 2));
+            else if (more) dma_stage((st + 2) % 3, 2 * cp + 2, 2 * (st + 2 - 9));
+            if (st == 0) dma_patch(1, 2 * cp + 1);                        // odd slab of this pair (first read in stage 4)
+            if (st == 5 && more) dma_patch(0, 2 * cp + 2);                // even slab of the next pair
+            stage_compute(st);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // the weights of stage g+1 (requested first thing in stage g-1) must have landed; younger requests may fly on
+            if (st == 0 || st == 1) { CY_WAIT_VM(2 + PROUNDS); }
+            else if (st == 5 || st == 6) { if (more) { CY_WAIT_VM(2 + PROUNDS); } else { CY_WAIT_VM(2); } }
+            else if (has_w) { CY_WAIT_VM(2); }
+            else { CY_WAIT_VM(0); }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    const int cbase = n0 + wn * 64 + fq * 16;
+    float bv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) bv[j] = a.bias[cbase + j];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        const int y = y0 + wm * 4 + (mi >> 1), x = x0 + (mi & 1) * 16 + fr;
+        if (y >= H || x >= W) continue;
+        const long pix = ((long)b * H + y) * W + x;
+        float v[16];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float t = acc[ni][mi][j] + bv[ni * 4 + j];
+                if (a.act) t = silu_fast(t);
+                v[ni * 4 + j] = t;
+            }
+        if (cbase + 16 <= a.Cout) {
+            f16* dst = reinterpret_cast<f16*>(a.out) + pix * a.out_ct + a.out_coff + cbase;
+            if (a.res) {
+                const f16* rp = reinterpret_cast<const f16*>(a.res) + pix * a.res_ct + a.res_coff + cbase;
+                const f16x8 r0v = *reinterpret_cast<const f16x8*>(rp), r1v = *reinterpret_cast<const f16x8*>(rp + 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { v[j] += (float)r0v[j]; v[8 + j] += (float)r1v[j]; }
+            }
+            f16x8 o0, o1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { o0[j] = (f16)v[j]; o1[j] = (f16)v[8 + j]; }
+            *reinterpret_cast<f16x8*>(dst) = o0;
+            *reinterpret_cast<f16x8*>(dst + 8) = o1;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int c = cbase + j;
+                if (c >= a.Cout) continue;
+                float t = v[j];
+                if (a.res) t += (float)(reinterpret_cast<const f16*>(a.res)[pix * a.res_ct + a.res_coff + c]);
+                reinterpret_cast<f16*>(a.out)[pix * a.out_ct + a.out_coff + c] = (f16)t;
+            }
+        }
+    }
+}
+
+static hipError_t launch_wide(const ConvArgs& a, hipStream_t s) {
+    constexpr int PR = 18 * 34, NPC = (PR + 15) / 16, PROUNDS = (NPC + 7) / 8;
+    const size_t lds = 2 * PROUNDS * 8 * 1024 + 3 * 2 * 128 * 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int blocks = a.B * ((a.Hi + 15) / 16) * ((a.Wi + 31) / 32) * ((pad64(a.Cout) + 127) / 128);
+    hipLaunchKernelGGL(conv3x3_wide_kernel, dim3(blocks), dim3(512), lds, s, a);
+    return hipGetLastError();
+}
+
 template <int WM, int RING, int PB = 2>
 static hipError_t launch_halo(const ConvArgs& a, hipStream_t s) {
     constexpr int TH = 4 * WM, NT = WM * 128;
@@ -1124,7 +1333,8 @@ static const char* const kVariantNames[CONV_NUM_VARIANTS] = {
     "conv_igemm_kernel<2,2,4> generic 128x128", "conv_igemm_kernel<4,1,2> generic 128x64",
     "conv3x3_halo2_kernel 3x3 s1 16x16px x128ch (halo<2,2> for odd slab counts)", "conv3x3_pp_kernel<2> 3x3 s1 16x16px x64ch",
     "conv3x3_pp_kernel<4> 3x3 s1 16x16px x128ch", "conv3x3_halo_kernel<4,*> 3x3 s1 16x16px x128ch",
-    "conv3x3_c64_kernel 3x3 s1 64->64 persistent", "conv_igemm_kernel<4,2,4,3> generic 256x128, 3-slab ring"};
+    "conv3x3_c64_kernel 3x3 s1 64->64 persistent", "conv_igemm_kernel<4,2,4,3> generic 256x128, 3-slab ring",
+    "conv3x3_wide_kernel 3x3 s1 16x32px x128ch, K slabs of 32"};
 const char* conv_variant_name(int v) { return v >= 0 && v < CONV_NUM_VARIANTS ? kVariantNames[v] : "?"; }
 
 int conv_variant(Precision p, const ConvArgs& a) {
@@ -1139,6 +1349,9 @@ int conv_variant(Precision p, const ConvArgs& a) {
         if (narrow) return force == 9 ? CONV_GENERIC_64 : CONV_PP_64;
         if (force == 5) return CONV_PP_128;
         if (force == 4 || force == 43) return CONV_HALO16_128;
+        static const int wide = getenv("CY_WIDE") ? atoi(getenv("CY_WIDE")) : 1;
+        const int wpad = (a.Wi + 31) / 32 * 32;
+        if (wide && a.wgt32 && (wpad - a.Wi) * 8 <= a.Wi) return CONV_WIDE_128;     // <= 12.5 % of the patch columns idle
         return CONV_HALO8_128;
     }
     if (narrow) return CONV_GENERIC_64;
@@ -1162,6 +1375,7 @@ hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s) {
             return v == 1 ? launch_halo<2, 3, 1>(b2, s) : launch_halo<2, 2>(b2, s);
         }
         case CONV_GENERIC_BIG: return launch_t<f16, 4, 2, 4, 3>(a, s);
+        case CONV_WIDE_128: return launch_wide(a, s);
         case CONV_GENERIC_64: return p == PREC_F16 ? launch_t<f16, 4, 1, 2>(a, s) : launch_t<float, 4, 1, 2>(a, s);
         default: return p == PREC_F16 ? launch_t<f16, 2, 2, 4>(a, s) : launch_t<float, 2, 2, 4>(a, s);
     }
@@ -1174,18 +1388,19 @@ void debug_read_stamps(unsigned long long* out8, bool reset) {
 }
 
 // ------------------------------------------------------------------------------------------------ weights
-// Packed layout ("slab-major"): [K chunk of 128 B][tap][row in Cout_pad64][128 B].  The unit every kernel stages -- the
+// Packed layout ("slab-major"): [K chunk of 128 B][tap][row in Cout_pad128][128 B] (zero rows past Cout, so no kernel
+// needs a range check on weight rows).  The unit every kernel stages -- the
 // rows n0..n0+BN of one (chunk, tap) -- is ONE contiguous run of BN*128 bytes, so a DMA wave-instruction (8 rows) reads
 // 1 KiB of consecutive cache lines instead of 8 lines a whole filter row (k*k*Cin elements) apart.  K is zero-padded to
 // a whole chunk; rows are permuted per 64 so that a lane of the MFMA result holds 16 contiguous output channels.
-size_t packed_weight_bytes(Precision p, int cout, int cin, int k) {
-    const int epb = p == PREC_F16 ? 64 : 32;
-    return (size_t)((cin + epb - 1) / epb) * k * k * pad64(cout) * 128;
+size_t packed_weight_bytes(Precision p, int cout, int cin, int k, int chunk_bytes) {
+    const int epb = chunk_bytes / (p == PREC_F16 ? 2 : 4);
+    return (size_t)((cin + epb - 1) / epb) * k * k * pad128(cout) * chunk_bytes;
 }
 
-void pack_weights(Precision p, const float* W, int cout, int cin, int k, void* dst) {
-    const int taps = k * k, cp = pad64(cout), epb = p == PREC_F16 ? 64 : 32, chunks = (cin + epb - 1) / epb;
-    memset(dst, 0, packed_weight_bytes(p, cout, cin, k));
+void pack_weights(Precision p, const float* W, int cout, int cin, int k, void* dst, int chunk_bytes) {
+    const int taps = k * k, cp = pad128(cout), epb = chunk_bytes / (p == PREC_F16 ? 2 : 4), chunks = (cin + epb - 1) / epb;
+    memset(dst, 0, packed_weight_bytes(p, cout, cin, k, chunk_bytes));
     for (int row = 0; row < cp; ++row) {
         const int blk = row >> 6, ni = (row >> 4) & 3, rr = row & 15;
         const int n = blk * 64 + (rr >> 2) * 16 + ni * 4 + (rr & 3);      // channel held by packed row `row`

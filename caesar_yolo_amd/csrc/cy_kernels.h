@@ -15,7 +15,8 @@ enum Precision { PREC_F16 = 0, PREC_F32 = 1 };
 struct ConvArgs {
     const void* in0; int in0_ct, in0_coff, c0, up0;   // segment 0: base, channels per pixel of the buffer, channel offset, #channels
     const void* in1; int in1_ct, in1_coff, c1;        // segment 1 (c1 == 0: absent)
-    const void* wgt;                                   // packed [K chunk][k*k][Cout_pad64][128 B]; rows permuted per 64 (pack_weights)
+    const void* wgt;                                   // packed [K chunk][k*k][Cout_pad128][128 B]; rows permuted per 64 (pack_weights)
+    const void* wgt32; uint32_t wgt32_bytes;           // second copy with 64-byte K chunks (3x3 s1 fp16 layers, conv3x3_wide_kernel) or null
     const float* bias;                                 // [Cout_pad64]
     void* out; int out_ct, out_coff;                   // NHWC destination slice
     int out_bs, out_ro;                                // destination pixel = b*out_bs + out_ro + (ho*Wo+wo)
@@ -38,7 +39,7 @@ struct PoolArgs {   // MaxPool2d(5,1,2) on a channel slice of an NHWC buffer, -i
 };
 
 hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s);
-enum ConvVariant { CONV_GENERIC_128 = 0, CONV_GENERIC_64, CONV_HALO8_128, CONV_PP_64, CONV_PP_128, CONV_HALO16_128, CONV_C64_PERSIST, CONV_GENERIC_BIG, CONV_NUM_VARIANTS };
+enum ConvVariant { CONV_GENERIC_128 = 0, CONV_GENERIC_64, CONV_HALO8_128, CONV_PP_64, CONV_PP_128, CONV_HALO16_128, CONV_C64_PERSIST, CONV_GENERIC_BIG, CONV_WIDE_128, CONV_NUM_VARIANTS };
 int conv_variant(Precision p, const ConvArgs& a);          // which kernel launch_conv picks
 const char* conv_variant_name(int v);
 void debug_read_stamps(unsigned long long* out8, bool reset);   // developer diagnostics (CY_DBG=64)
@@ -48,10 +49,11 @@ hipError_t launch_pool5(Precision p, const PoolArgs& a, hipStream_t s);
 // Host-side weight packing into the layout launch_conv expects.
 //   W: [Cout][Cin][k][k] fp32 -> dst: [Cout_pad64][k*k][Cin] (fp16 or fp32), rows permuted within each 64-row group
 //   so that MFMA row (ni, rr) holds channel 64*blk + 16*(rr>>2) + 4*ni + (rr&3).
-size_t packed_weight_bytes(Precision p, int cout, int cin, int k);
-void pack_weights(Precision p, const float* W, int cout, int cin, int k, void* dst);
+size_t packed_weight_bytes(Precision p, int cout, int cin, int k, int chunk_bytes = 128);
+void pack_weights(Precision p, const float* W, int cout, int cin, int k, void* dst, int chunk_bytes = 128);
 void pack_stem_weights(const float* W, int cout, void* dst);      // 64*32 fp16
 __host__ __device__ inline int pad64(int c) { return (c + 63) / 64 * 64; }
+__host__ __device__ inline int pad128(int c) { return (c + 127) / 128 * 128; }
 
 // ---- detection post-processing --------------------------------------------------------------
 struct DecodeArgs {

@@ -12,7 +12,7 @@
 
 using namespace cy;
 
-struct DevConv { void* w = nullptr; float* bias = nullptr; size_t wbytes = 0; float* stem_w = nullptr; };
+struct DevConv { void* w = nullptr; float* bias = nullptr; size_t wbytes = 0; float* stem_w = nullptr; void* w32 = nullptr; size_t w32bytes = 0; };
 
 struct cy_ctx {
     int device = 0;
@@ -72,7 +72,7 @@ size_t tensor_elems_per_tile(const Plan& p, int H, int W) {
 void free_all(cy_ctx* c) {
     for (auto e : c->ev_pool) hipEventDestroy(e);
     c->ev_pool.clear(); c->ev_used = 0; c->prof.clear();
-    for (auto& d : c->dconv) { if (d.w) hipFree(d.w); if (d.bias) hipFree(d.bias); if (d.stem_w) hipFree(d.stem_w); }
+    for (auto& d : c->dconv) { if (d.w) hipFree(d.w); if (d.bias) hipFree(d.bias); if (d.stem_w) hipFree(d.stem_w); if (d.w32) hipFree(d.w32); }
     c->dconv.clear();
     if (c->ws) hipFree(c->ws);
     c->ws = nullptr;
@@ -149,6 +149,13 @@ int upload_weights(cy_ctx* c, const void* buf, size_t nbytes) {
         pack_weights(c->prec, W, co, ci, k, packed.data());
         HIPCHK(c, hipMalloc(&dc.w, dc.wbytes));
         HIPCHK(c, hipMemcpy(dc.w, packed.data(), dc.wbytes, hipMemcpyHostToDevice));
+        if (c->prec == PREC_F16 && k == 3 && s == 1 && ci % 64 == 0 && co >= 128) {   // second copy for conv3x3_wide_kernel
+            dc.w32bytes = packed_weight_bytes(c->prec, co, ci, k, 64);
+            packed.resize(dc.w32bytes);
+            pack_weights(c->prec, W, co, ci, k, packed.data(), 64);
+            HIPCHK(c, hipMalloc(&dc.w32, dc.w32bytes));
+            HIPCHK(c, hipMemcpy(dc.w32, packed.data(), dc.w32bytes, hipMemcpyHostToDevice));
+        }
     }
     c->plan = plan; c->names = names;
     // ---- workspace for (max_batch, max_h, max_w)
@@ -381,6 +388,7 @@ int cy_forward(cy_ctx* c, const void* d_netin, int B, int H, int W, float* d_pre
                 lev_in = t1.level;
             }
             a.wgt = c->dconv[o.conv].w; a.wgt_bytes = (uint32_t)c->dconv[o.conv].wbytes; a.bias = c->dconv[o.conv].bias;
+            a.wgt32 = c->dconv[o.conv].w32; a.wgt32_bytes = (uint32_t)c->dconv[o.conv].w32bytes;
             a.B = Bn; a.Hi = H >> lev_in; a.Wi = W >> lev_in; a.k = d.k; a.s = d.s; a.act = d.act;
             a.Ho = d.s == 2 ? a.Hi / 2 : a.Hi; a.Wo = d.s == 2 ? a.Wi / 2 : a.Wi;
             a.Cin = d.cin; a.Cout = d.cout;
@@ -487,17 +495,25 @@ int cy_conv_bn_silu(cy_ctx* c, const void* d_in, int B, int Hi, int Wi, int Cin,
     HIPCHK(c, hipMalloc(&db, 4 * cp));
     HIPCHK(c, hipMemcpy(dw, packed.data(), wb, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(db, bias.data(), 4 * cp, hipMemcpyHostToDevice));
+    void* dw32 = nullptr; size_t wb32 = 0;
+    if (c->prec == PREC_F16 && k == 3 && s == 1 && Cin % 64 == 0 && Cout >= 128) {
+        wb32 = packed_weight_bytes(c->prec, Cout, Cin, k, 64);
+        std::vector<char> p32(wb32);
+        pack_weights(c->prec, h_w, Cout, Cin, k, p32.data(), 64);
+        HIPCHK(c, hipMalloc(&dw32, wb32));
+        HIPCHK(c, hipMemcpy(dw32, p32.data(), wb32, hipMemcpyHostToDevice));
+    }
     ConvArgs a{};
     const int pad = k / 2;
     a.in0 = d_in; a.in0_ct = Cin; a.c0 = Cin; a.in0_bytes = (uint32_t)((size_t)B * Hi * Wi * Cin * es);
-    a.wgt = dw; a.wgt_bytes = (uint32_t)wb; a.bias = db;
+    a.wgt = dw; a.wgt_bytes = (uint32_t)wb; a.bias = db; a.wgt32 = dw32; a.wgt32_bytes = (uint32_t)wb32;
     a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ho = (Hi + 2 * pad - k) / s + 1; a.Wo = (Wi + 2 * pad - k) / s + 1;
     a.Cin = Cin; a.Cout = Cout; a.k = k; a.s = s; a.act = act;
     a.out = d_out; a.out_ct = Cout; a.out_bs = a.Ho * a.Wo;
     if (d_res) { a.res = d_res; a.res_ct = Cout; }
     hipError_t e = launch_conv(c->prec, a, (hipStream_t)stream);
     hipError_t e2 = hipStreamSynchronize((hipStream_t)stream);
-    hipFree(dw); hipFree(db);
+    hipFree(dw); hipFree(db); if (dw32) hipFree(dw32);
     if (e != hipSuccess) return fail(c, CY_ERR_HIP, hipGetErrorString(e));
     if (e2 != hipSuccess) return fail(c, CY_ERR_HIP, hipGetErrorString(e2));
     return CY_OK;

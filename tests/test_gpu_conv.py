@@ -31,6 +31,9 @@ CASES = [  # B, H, W, Cin, Cout, k, s, act, residual
     (3, 120, 100, 192, 160, 1, 1, True, True),    # ring kernel: ragged pixel tail (M % 256 != 0), ragged Cout, residual
     (2, 256, 256, 64, 256, 3, 2, True, False),    # ring kernel: 3x3 stride 2 (im2col gather with padding masks)
     (16, 64, 64, 64, 128, 1, 1, False, False),    # ring kernel: a single K-slab (prologue shorter than the ring)
+    (2, 40, 64, 256, 192, 3, 1, True, True),      # 512-px wide kernel: ragged rows, Cout 192 (half-empty channel tile), residual, 4 slab pairs
+    (1, 16, 32, 128, 128, 3, 1, False, False),    # wide kernel: a single patch, two slab pairs, no activation
+    (3, 30, 60, 64, 256, 3, 1, True, False),      # wide kernel: ragged columns (60 of 64) and rows, one slab pair
 ]
 
 
