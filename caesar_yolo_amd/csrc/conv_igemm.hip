@@ -937,15 +937,14 @@ __global__ __launch_bounds__(512) void conv3x3_halo2_kernel(const ConvArgs a) {
     auto dma_patch = [&](int buf, int ch) {
 #pragma unroll
         for (int j = 0; j < PROUNDS; ++j) {
-            const unsigned off = poff[j] == CY_OOB ? CY_OOB : poff[j] + (unsigned)(ch * 128);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_void*)(Pbuf + buf * P_BYTES + (j * NW + wave) * 1024), 16, off, 0, 0, 0);
+            // the uniform part of the offset goes in soffset, which is not range-checked: an OOB sentinel stays OOB
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_void*)(Pbuf + buf * P_BYTES + (j * NW + wave) * 1024), 16, poff[j], ch * 128, 0, 0);
         }
     };
     auto dma_slab = [&](int buf, int t, int ch, int tap) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const unsigned off = woff[j] + (unsigned)((ch * 9 + tap) * cpad * 128);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)(Wbuf + buf * W_BYTES + t * SLAB + (j * NW + wave) * 1024), 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)(Wbuf + buf * W_BYTES + t * SLAB + (j * NW + wave) * 1024), 16, woff[j], (ch * 9 + tap) * cpad * 128, 0, 0);
         }
     };
     f32x4 acc[4][4];
@@ -1099,6 +1098,7 @@ static hipError_t launch_halo2(const ConvArgs& a, hipStream_t s) {
 // deep enough to request weights two stages ahead (counted vmcnt; halo pieces stay in flight for 2-3 stages).
 // 64-byte rows: chunk' = chunk ^ 2*((row>>2)&1) is conflict-free for the ds_read_b128 lane groups at any row offset.
 // Weights come from the second packed copy with 64-byte K chunks (ConvArgs::wgt32).
+template <bool TAIL>
 __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
     constexpr int TH = 16, TW = 32, NW = 8, BN = 128, PWID = TW + 2;
     constexpr int PR = (TH + 2) * PWID, NPC = (PR + 15) / 16, PROUNDS = (NPC + NW - 1) / NW;
@@ -1142,17 +1142,14 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
     }
     auto dma_patch = [&](int buf, int slab) {               // slab: 32-channel slab index
 #pragma unroll
-        for (int j = 0; j < PROUNDS; ++j) {
-            const unsigned off = poff[j] == CY_OOB ? CY_OOB : poff[j] + (unsigned)(slab * 64);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_void*)(Pbuf + buf * P_BYTES + (j * NW + wave) * 1024), 16, off, 0, 0, 0);
-        }
+        for (int j = 0; j < PROUNDS; ++j)                    // uniform part in soffset: not range-checked, so the OOB sentinel of
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_void*)(Pbuf + buf * P_BYTES + (j * NW + wave) * 1024), 16, poff[j], slab * 64, 0, 0);   // a lane survives it
     };
     auto dma_stage = [&](int ring, int slab0, int u0) {     // taps u0, u0+1 of the pair starting at slab slab0 (u in 0..17)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int u = u0 + t, sl = slab0 + u / 9, tap = u % 9;
-            const unsigned off = woff + (unsigned)((sl * 9 + tap) * cpad * 64);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)(Wbuf + ring * W_BYTES + t * SLAB + wave * 1024), 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)(Wbuf + ring * W_BYTES + t * SLAB + wave * 1024), 16, woff, (sl * 9 + tap) * cpad * 64, 0, 0);
         }
     };
     f32x4 acc[4][8];
@@ -1207,7 +1204,7 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
         load_x(xa[1], p1, t1 / 3, t1 % 3, 1);
         mma(wb[1], xa[0], 0);
         __builtin_amdgcn_sched_barrier(0);
-        mma(wb[1], xa[1], 1);
+        if (!TAIL) mma(wb[1], xa[1], 1);                     // TAIL: the last 16 MFMAs are issued behind the stage barrier
     };
 
     // prologue: halo of slab 0, weight stages 0 and 1
@@ -1237,6 +1234,7 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
+            if (TAIL) mma(wb[1], xa[1], 1);                  // operands are in registers: overlaps the next stage's DMA issue / first reads
         }
     }
 
@@ -1289,11 +1287,14 @@ static hipError_t launch_wide(const ConvArgs& a, hipStream_t s) {
     const size_t lds = 2 * PROUNDS * 8 * 1024 + 3 * 2 * 128 * 64;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wide_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wide_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const int blocks = a.B * ((a.Hi + 15) / 16) * ((a.Wi + 31) / 32) * ((pad64(a.Cout) + 127) / 128);
-    hipLaunchKernelGGL(conv3x3_wide_kernel, dim3(blocks), dim3(512), lds, s, a);
+    static const int tail = getenv("CY_WIDE_TAIL") ? atoi(getenv("CY_WIDE_TAIL")) : 1;
+    if (tail) hipLaunchKernelGGL(conv3x3_wide_kernel<true>, dim3(blocks), dim3(512), lds, s, a);
+    else hipLaunchKernelGGL(conv3x3_wide_kernel<false>, dim3(blocks), dim3(512), lds, s, a);
     return hipGetLastError();
 }
 
