@@ -67,6 +67,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // four waves per CU hide each other's drains).  NSTAGE = 3 (the 256x128 tile, eight waves, one workgroup per CU): slabs
 // are requested TWO steps ahead and the wait before a barrier is a counted vmcnt that leaves the newest request in
 // flight, so an L2 round trip (about one step's worth of MFMA time for K-slabs of 64) is off the critical path.
+// Non-template wrappers: inside a template kernel a buffer builtin whose soffset is not a constant makes this clang drop
+// the kernel's host-side instantiation without a diagnostic; called through these, the builtin is never value-dependent.
+typedef __attribute__((address_space(3))) void lds_ptr_t;
+__device__ __forceinline__ void dma_piece(__amdgpu_buffer_rsrc_t rs, lds_ptr_t* dst, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, voff, soff, 0, 0);     // soffset is NOT range-checked (voffset is)
+}
+__device__ __forceinline__ u32x4 load_b128(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+}
+
 template <typename T, int WM, int WN, int MI, int NSTAGE = 2>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_igemm_kernel(const ConvArgs a) {
     constexpr int BM = WM * MI * 16, BN = WN * 64, NT = WM * WN * 64, RPR = NT / 8;
@@ -1298,6 +1308,203 @@ static hipError_t launch_wide(const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ 1x1, pixels direct to registers
+// A 1x1 convolution has no tap reuse, so staging the pixel operand through LDS only costs: in the tiled kernels above two
+// thirds of the LDS-DMA pieces (60-180 issue cycles each) carry pixels that exactly one wave reads exactly once.  In NHWC
+// the MFMA B-operand fragment of a lane (pixel fr, channels 8*(fq+4*kk)..+7) is 16 contiguous bytes in global memory, so
+// here every wave loads its own pixels straight into registers (buffer_load_dwordx4, zero fill from the range check,
+// RING-1 K chunks ahead) and only the weights - shared by all eight waves - go through LDS (RING slots, requested RING-1
+// chunks ahead, counted vmcnt).  A wave owns MI*16 pixels x all BN = 64*NB channels of the workgroup's tile:
+//   per 64-channel K chunk and wave: NB DMA pieces + 2*MI register loads for 8*NB*MI MFMAs (NB=4, MI=2: 8 for 64).
+// Also handles the two-segment input (nearest-x2 upsample + concat) of layers 12 and 15: per-lane addresses anyway.
+template <int NB, int MI, int RING>
+__global__ __launch_bounds__(512) void conv1x1_direct_kernel(const ConvArgs a) {
+    constexpr int NW = 8, BN = 64 * NB, BM = NW * MI * 16, W_BYTES = BN * 128, DIST = RING - 1;
+    constexpr int WPW = BN / 8 / NW, APW = 2 * MI, PER = WPW + APW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void lds_void;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int HoWo = a.Ho * a.Wo, M = a.B * HoWo;
+    const int cpad = pad128(a.Cout);
+    const int ntn = (pad64(a.Cout) + BN - 1) / BN;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (id / ntn) * BM, n0 = (id % ntn) * BN;
+    const int chunks = a.Cin / 64, c0chunks = a.c1 ? a.c0 / 64 : chunks;
+
+    const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in0), 0, a.in0_bytes, 0x00020000);
+    const auto rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.c1 ? a.in1 : a.in0), 0,
+                                                       a.c1 ? a.in1_bytes : a.in0_bytes, 0x00020000);
+    const auto rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wgt), 0, a.wgt_bytes, 0x00020000);
+    unsigned v0[MI], v1[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = m0 + (wave * MI + mi) * 16 + fr;
+        v0[mi] = v1[mi] = CY_OOB;
+        if (m < M) {
+            int p0 = m;
+            if (a.up0) {
+                const int b = m / HoWo, r = m - b * HoWo, ho = r / a.Wo, wo = r - ho * a.Wo;
+                p0 = (b * (a.Hi >> 1) + (ho >> 1)) * (a.Wi >> 1) + (wo >> 1);
+            }
+            v0[mi] = (unsigned)(p0 * a.in0_ct + a.in0_coff + fq * 8) * 2u;
+            v1[mi] = (unsigned)(m * a.in1_ct + a.in1_coff + fq * 8) * 2u;
+        }
+    }
+    unsigned woff[WPW];
+#pragma unroll
+    for (int j = 0; j < WPW; ++j) {
+        const int row = (j * NW + wave) * 8 + (lane >> 3);
+        woff[j] = (unsigned)((n0 + row) * 128 + ((lane & 7) ^ (row & 7)) * 16);
+    }
+    u32x4 xa[RING][MI][2];
+    auto load_a = [&](int slot, int c) {                    // the uniform K offset rides in soffset (not range-checked)
+        if (c >= c0chunks) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+                    xa[slot][mi][kk] = load_b128(rs1, v1[mi], ((c - c0chunks) * 64 + kk * 32) * 2);
+        } else {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+                    xa[slot][mi][kk] = load_b128(rs0, v0[mi], (c * 64 + kk * 32) * 2);
+        }
+    };
+    auto dma_w = [&](int slot, int c) {
+#pragma unroll
+        for (int j = 0; j < WPW; ++j)
+            dma_piece(rsw, (lds_ptr_t*)(smem + slot * W_BYTES + (j * NW + wave) * 1024), woff[j], c * cpad * 128);
+    };
+    f32x4 acc[NB * 4][MI];
+#pragma unroll
+    for (int ni = 0; ni < NB * 4; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](int slot) {
+        const char* Wb = smem + slot * W_BYTES;
+        // 2*NB groups of (4 weight fragments, 4*MI MFMAs); the fragments of group i+1 are read before the MFMAs of group i
+        f16x8 wb[2][4];
+        auto load_wb = [&](f16x8* dst, int gi) {
+            const int kk = gi / NB, g = gi % NB, qf = fq + 4 * kk;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int r = g * 64 + ni * 16 + fr;
+                dst[ni] = *reinterpret_cast<const f16x8*>(Wb + r * 128 + ((qf ^ (r & 7)) << 4));
+            }
+        };
+        load_wb(wb[0], 0);
+#pragma unroll
+        for (int gi = 0; gi < 2 * NB; ++gi) {
+            const int kk = gi / NB, g = gi % NB;
+            if (gi + 1 < 2 * NB) load_wb(wb[(gi + 1) & 1], gi + 1);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+                    acc[g * 4 + ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                        wb[gi & 1][ni], __builtin_bit_cast(f16x8, xa[slot][mi][kk]), acc[g * 4 + ni][mi], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // prologue: chunks 0..DIST-1 requested (weights first, then pixels, per chunk: the order the counted waits assume)
+#pragma unroll
+    for (int d = 0; d < DIST; ++d)
+        if (d < chunks) { dma_w(d, d); load_a(d, d); }
+    // weights of chunk 0 landed; what was requested after them may stay in flight (DIST is 2 or 3)
+    if (chunks >= DIST) { CY_WAIT_VM(APW + (DIST - 1) * PER); }
+    else if (DIST == 3 && chunks == 2) { CY_WAIT_VM(APW + PER); }
+    else { CY_WAIT_VM(APW); }
+    __builtin_amdgcn_s_barrier();
+#pragma unroll 1
+    for (int cb = 0; cb < chunks; cb += RING) {
+#pragma unroll
+        for (int u = 0; u < RING; ++u) {
+            const int c = cb + u;
+            if (c < chunks) {
+                if (c + DIST < chunks) { dma_w((u + DIST) % RING, c + DIST); load_a((u + DIST) % RING, c + DIST); }
+                compute(u);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                // weights of chunk c+1 must have landed; everything requested after them may stay in flight
+                if (c + DIST < chunks) { CY_WAIT_VM(APW + (DIST - 1) * PER); }
+                else if (DIST == 3 && c + 2 < chunks) { CY_WAIT_VM(APW + PER); }
+                else { CY_WAIT_VM(APW); }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    // ---- epilogue: per 64-channel block the same 16-contiguous-channels-per-lane layout as the other kernels
+#pragma unroll
+    for (int g = 0; g < NB; ++g) {
+        const int cbase = n0 + g * 64 + fq * 16;
+        if (cbase >= pad64(a.Cout)) continue;
+        float bv[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) bv[j] = a.bias[cbase + j];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int m = m0 + (wave * MI + mi) * 16 + fr;
+            if (m >= M) continue;
+            const int b = m / HoWo, r = m - b * HoWo;
+            const long opix = (long)b * a.out_bs + a.out_ro + r;
+            float v[16];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float t = acc[g * 4 + ni][mi][j] + bv[ni * 4 + j];
+                    if (a.act) t = silu_fast(t);
+                    v[ni * 4 + j] = t;
+                }
+            if (cbase + 16 <= a.Cout) {
+                f16* dst = reinterpret_cast<f16*>(a.out) + opix * a.out_ct + a.out_coff + cbase;
+                if (a.res) {
+                    const f16* rp = reinterpret_cast<const f16*>(a.res) + (long)m * a.res_ct + a.res_coff + cbase;
+                    const f16x8 r0v = *reinterpret_cast<const f16x8*>(rp), r1v = *reinterpret_cast<const f16x8*>(rp + 8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { v[j] += (float)r0v[j]; v[8 + j] += (float)r1v[j]; }
+                }
+                f16x8 o0, o1;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { o0[j] = (f16)v[j]; o1[j] = (f16)v[8 + j]; }
+                *reinterpret_cast<f16x8*>(dst) = o0;
+                *reinterpret_cast<f16x8*>(dst + 8) = o1;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int c = cbase + j;
+                    if (c >= a.Cout) continue;
+                    float t = v[j];
+                    if (a.res) t += (float)(reinterpret_cast<const f16*>(a.res)[(long)m * a.res_ct + a.res_coff + c]);
+                    reinterpret_cast<f16*>(a.out)[opix * a.out_ct + a.out_coff + c] = (f16)t;
+                }
+            }
+        }
+    }
+}
+
+template <int NB, int MI, int RING>
+static hipError_t launch_direct(const ConvArgs& a, hipStream_t s) {
+    constexpr int BN = 64 * NB, BM = 8 * MI * 16;
+    const size_t lds = RING * BN * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_direct_kernel<NB, MI, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int M = a.B * a.Ho * a.Wo;
+    const int blocks = ((M + BM - 1) / BM) * ((pad64(a.Cout) + BN - 1) / BN);
+    hipLaunchKernelGGL((conv1x1_direct_kernel<NB, MI, RING>), dim3(blocks), dim3(512), lds, s, a);
+    return hipGetLastError();
+}
+
 template <int WM, int RING, int PB = 2>
 static hipError_t launch_halo(const ConvArgs& a, hipStream_t s) {
     constexpr int TH = 4 * WM, NT = WM * 128;
@@ -1335,7 +1542,8 @@ static const char* const kVariantNames[CONV_NUM_VARIANTS] = {
     "conv3x3_halo2_kernel 3x3 s1 16x16px x128ch (halo<2,2> for odd slab counts)", "conv3x3_pp_kernel<2> 3x3 s1 16x16px x64ch",
     "conv3x3_pp_kernel<4> 3x3 s1 16x16px x128ch", "conv3x3_halo_kernel<4,*> 3x3 s1 16x16px x128ch",
     "conv3x3_c64_kernel 3x3 s1 64->64 persistent", "conv_igemm_kernel<4,2,4,3> generic 256x128, 3-slab ring",
-    "conv3x3_wide_kernel 3x3 s1 16x32px x128ch, K slabs of 32"};
+    "conv3x3_wide_kernel 3x3 s1 16x32px x128ch, K slabs of 32",
+    "conv1x1_direct_kernel<4,2> 1x1 256px x256ch, pixels to regs", "conv1x1_direct_kernel<2,2> 1x1 256px x128ch, pixels to regs"};
 const char* conv_variant_name(int v) { return v >= 0 && v < CONV_NUM_VARIANTS ? kVariantNames[v] : "?"; }
 
 int conv_variant(Precision p, const ConvArgs& a) {
@@ -1356,6 +1564,15 @@ int conv_variant(Precision p, const ConvArgs& a) {
         return CONV_HALO8_128;
     }
     if (narrow) return CONV_GENERIC_64;
+    // 1x1: pixels-direct kernel once there is at least one 256-pixel tile per CU (below that the 128x128 tiles of the generic
+    // kernel fill the chip better).  CY_DIRECT_MIN_BLOCKS is read per call so that the parity tests can force the path.
+    if (p == PREC_F16 && a.k == 1 && a.s == 1 && !a.out_f32 && a.Cin % 64 == 0 && (a.c1 == 0 || a.c0 % 64 == 0)) {
+        const char* e = getenv("CY_DIRECT_MIN_BLOCKS");
+        const long min_blocks = e ? atol(e) : 256;
+        const int bn = pad64(a.Cout) >= 256 ? 256 : 128;
+        const long blocks = (((long)a.B * a.Ho * a.Wo + 255) / 256) * ((pad64(a.Cout) + bn - 1) / bn);
+        if (min_blocks >= 0 && blocks >= min_blocks) return bn == 256 ? CONV_DIRECT_256 : CONV_DIRECT_128;
+    }
     // 1x1 and strided convs with enough 256-pixel tiles to fill the chip: deeper-pipelined 256x128 tile
     static const int big = getenv("CY_BIG") ? atoi(getenv("CY_BIG")) : 1;
     const long M = (long)a.B * a.Ho * a.Wo;
@@ -1377,6 +1594,8 @@ hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s) {
         }
         case CONV_GENERIC_BIG: return launch_t<f16, 4, 2, 4, 3>(a, s);
         case CONV_WIDE_128: return launch_wide(a, s);
+        case CONV_DIRECT_256: return launch_direct<4, 2, 3>(a, s);
+        case CONV_DIRECT_128: return launch_direct<2, 2, 4>(a, s);
         case CONV_GENERIC_64: return p == PREC_F16 ? launch_t<f16, 4, 1, 2>(a, s) : launch_t<float, 4, 1, 2>(a, s);
         default: return p == PREC_F16 ? launch_t<f16, 2, 2, 4>(a, s) : launch_t<float, 2, 2, 4>(a, s);
     }
