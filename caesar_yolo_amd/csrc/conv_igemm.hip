@@ -1308,7 +1308,7 @@ static hipError_t launch_wide(const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-// ------------------------------------------------------------------------------------------------ 1x1, pixels direct to registers
+// ------------------------------------------------------------------------------------------------ 1x1 (and 3x3 stride 2), pixels direct to registers
 // A 1x1 convolution has no tap reuse, so staging the pixel operand through LDS only costs: in the tiled kernels above two
 // thirds of the LDS-DMA pieces (60-180 issue cycles each) carry pixels that exactly one wave reads exactly once.  In NHWC
 // the MFMA B-operand fragment of a lane (pixel fr, channels 8*(fq+4*kk)..+7) is 16 contiguous bytes in global memory, so
@@ -1317,7 +1317,7 @@ static hipError_t launch_wide(const ConvArgs& a, hipStream_t s) {
 // chunks ahead, counted vmcnt).  A wave owns MI*16 pixels x all BN = 64*NB channels of the workgroup's tile:
 //   per 64-channel K chunk and wave: NB DMA pieces + 2*MI register loads for 8*NB*MI MFMAs (NB=4, MI=2: 8 for 64).
 // Also handles the two-segment input (nearest-x2 upsample + concat) of layers 12 and 15: per-lane addresses anyway.
-template <int NB, int MI, int RING>
+template <int NB, int MI, int RING, bool K3>
 __global__ __launch_bounds__(512) void conv1x1_direct_kernel(const ConvArgs a) {
     constexpr int NW = 8, BN = 64 * NB, BM = NW * MI * 16, W_BYTES = BN * 128, DIST = RING - 1;
     constexpr int WPW = BN / 8 / NW, APW = 2 * MI, PER = WPW + APW;
@@ -1331,25 +1331,42 @@ __global__ __launch_bounds__(512) void conv1x1_direct_kernel(const ConvArgs a) {
     const int ntn = (pad64(a.Cout) + BN - 1) / BN;
     const int id = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (id / ntn) * BM, n0 = (id % ntn) * BN;
-    const int chunks = a.Cin / 64, c0chunks = a.c1 ? a.c0 / 64 : chunks;
+    // K chunk c = slab * taps + tap (the order of the packed weights).  k = 3 (strided 3x3 layers): every tap is the same
+    // per-lane centre-pixel address plus a UNIFORM shift, which rides in soffset; soffset is unsigned, so the resource base
+    // is moved back by the largest negative shift (one row + one pixel) and the shift is biased by the same amount.  Lanes
+    // whose tap falls outside the image get the OOB sentinel in voffset (the only part that is range-checked) -> zeros.
+    // K3 = false is the plain 1x1 kernel: none of the tap arithmetic is compiled in.
+    constexpr int taps = K3 ? 9 : 1, pad = K3 ? 1 : 0, kk3 = K3 ? 3 : 1;
+    const int chunks = (a.Cin / 64) * taps, c0chunks = a.c1 ? a.c0 / 64 : chunks;
+    const unsigned bias_bytes = K3 ? (unsigned)((a.Wi + 1) * a.in0_ct) * 2u : 0u;
 
-    const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in0), 0, a.in0_bytes, 0x00020000);
+    // (num_records widened by the bias so that the check passes whether or not the hardware adds soffset before it)
+    const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.in0)) - bias_bytes, 0,
+                                                       a.in0_bytes + 2 * bias_bytes, 0x00020000);
     const auto rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.c1 ? a.in1 : a.in0), 0,
                                                        a.c1 ? a.in1_bytes : a.in0_bytes, 0x00020000);
     const auto rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wgt), 0, a.wgt_bytes, 0x00020000);
-    unsigned v0[MI], v1[MI];
+    unsigned v0[MI], v1[MI], vmask[MI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int m = m0 + (wave * MI + mi) * 16 + fr;
         v0[mi] = v1[mi] = CY_OOB;
+        vmask[mi] = 0;
         if (m < M) {
-            int p0 = m;
-            if (a.up0) {
-                const int b = m / HoWo, r = m - b * HoWo, ho = r / a.Wo, wo = r - ho * a.Wo;
-                p0 = (b * (a.Hi >> 1) + (ho >> 1)) * (a.Wi >> 1) + (wo >> 1);
-            }
+            const int b = m / HoWo, r = m - b * HoWo, ho = r / a.Wo, wo = r - ho * a.Wo;
+            int p0;
+            if (a.up0) p0 = (b * (a.Hi >> 1) + (ho >> 1)) * (a.Wi >> 1) + (wo >> 1);
+            else p0 = (b * a.Hi + ho * a.s) * a.Wi + wo * a.s;                      // centre tap: always inside the image
             v0[mi] = (unsigned)(p0 * a.in0_ct + a.in0_coff + fq * 8) * 2u;
             v1[mi] = (unsigned)(m * a.in1_ct + a.in1_coff + fq * 8) * 2u;
+            unsigned vm = 0;
+#pragma unroll
+            for (int kh = 0; kh < kk3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < kk3; ++kw)
+                    if ((unsigned)(ho * a.s + kh - pad) < (unsigned)a.Hi && (unsigned)(wo * a.s + kw - pad) < (unsigned)a.Wi)
+                        vm |= 1u << (kh * kk3 + kw);
+            vmask[mi] = vm;
         }
     }
     unsigned woff[WPW];
@@ -1359,19 +1376,30 @@ __global__ __launch_bounds__(512) void conv1x1_direct_kernel(const ConvArgs a) {
         woff[j] = (unsigned)((n0 + row) * 128 + ((lane & 7) ^ (row & 7)) * 16);
     }
     u32x4 xa[RING][MI][2];
-    auto load_a = [&](int slot, int c) {                    // the uniform K offset rides in soffset (not range-checked)
+    int ltap = 0, lslab = 0;                                // cursor of load_a (called for c = 0, 1, 2, ... in order)
+    auto load_a = [&](int slot, int c) {                    // the uniform part of the address rides in soffset (not range-checked)
         if (c >= c0chunks) {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk)
                     xa[slot][mi][kk] = load_b128(rs1, v1[mi], ((c - c0chunks) * 64 + kk * 32) * 2);
-        } else {
+        } else if constexpr (!K3) {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk)
                     xa[slot][mi][kk] = load_b128(rs0, v0[mi], (c * 64 + kk * 32) * 2);
+        } else {
+            const int kh = ltap / 3, kw = ltap - kh * 3;
+            const unsigned so = bias_bytes + (unsigned)((((kh - 1) * a.Wi + (kw - 1)) * a.in0_ct + lslab * 64) * 2);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const unsigned vo = ((vmask[mi] >> ltap) & 1u) ? v0[mi] : CY_OOB;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) xa[slot][mi][kk] = load_b128(rs0, vo, so + kk * 64);
+            }
+            if (++ltap == 9) { ltap = 0; ++lslab; }
         }
     };
     auto dma_w = [&](int slot, int c) {
@@ -1490,18 +1518,18 @@ __global__ __launch_bounds__(512) void conv1x1_direct_kernel(const ConvArgs a) {
     }
 }
 
-template <int NB, int MI, int RING>
+template <int NB, int MI, int RING, bool K3>
 static hipError_t launch_direct(const ConvArgs& a, hipStream_t s) {
     constexpr int BN = 64 * NB, BM = 8 * MI * 16;
     const size_t lds = RING * BN * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_direct_kernel<NB, MI, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_direct_kernel<NB, MI, RING, K3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const int M = a.B * a.Ho * a.Wo;
     const int blocks = ((M + BM - 1) / BM) * ((pad64(a.Cout) + BN - 1) / BN);
-    hipLaunchKernelGGL((conv1x1_direct_kernel<NB, MI, RING>), dim3(blocks), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((conv1x1_direct_kernel<NB, MI, RING, K3>), dim3(blocks), dim3(512), lds, s, a);
     return hipGetLastError();
 }
 
@@ -1546,6 +1574,8 @@ static const char* const kVariantNames[CONV_NUM_VARIANTS] = {
     "conv1x1_direct_kernel<4,2> 1x1 256px x256ch, pixels to regs", "conv1x1_direct_kernel<2,2> 1x1 256px x128ch, pixels to regs"};
 const char* conv_variant_name(int v) { return v >= 0 && v < CONV_NUM_VARIANTS ? kVariantNames[v] : "?"; }
 
+static bool s2_direct() { static const int v = getenv("CY_S2_DIRECT") ? atoi(getenv("CY_S2_DIRECT")) : 1; return v != 0; }
+
 int conv_variant(Precision p, const ConvArgs& a) {
     const bool narrow = pad64(a.Cout) <= 64;
     // 3x3 stride-1 layers (fp16 context; the fp32 parity context keeps the generic kernel): halo-reuse kernels.
@@ -1566,7 +1596,8 @@ int conv_variant(Precision p, const ConvArgs& a) {
     if (narrow) return CONV_GENERIC_64;
     // 1x1: pixels-direct kernel once there is at least one 256-pixel tile per CU (below that the 128x128 tiles of the generic
     // kernel fill the chip better).  CY_DIRECT_MIN_BLOCKS is read per call so that the parity tests can force the path.
-    if (p == PREC_F16 && a.k == 1 && a.s == 1 && !a.out_f32 && a.Cin % 64 == 0 && (a.c1 == 0 || a.c0 % 64 == 0)) {
+    if (p == PREC_F16 && !a.out_f32 && a.Cin % 64 == 0 &&
+        ((a.k == 1 && a.s == 1 && (a.c1 == 0 || a.c0 % 64 == 0)) || (a.k == 3 && a.s == 2 && a.c1 == 0 && !a.up0 && a.Cin >= 128 && s2_direct()))) {
         const char* e = getenv("CY_DIRECT_MIN_BLOCKS");
         const long min_blocks = e ? atol(e) : 256;
         const int bn = pad64(a.Cout) >= 256 ? 256 : 128;
@@ -1594,8 +1625,8 @@ hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s) {
         }
         case CONV_GENERIC_BIG: return launch_t<f16, 4, 2, 4, 3>(a, s);
         case CONV_WIDE_128: return launch_wide(a, s);
-        case CONV_DIRECT_256: return launch_direct<4, 2, 3>(a, s);
-        case CONV_DIRECT_128: return launch_direct<2, 2, 4>(a, s);
+        case CONV_DIRECT_256: return a.k == 3 ? launch_direct<4, 2, 3, true>(a, s) : launch_direct<4, 2, 3, false>(a, s);
+        case CONV_DIRECT_128: return a.k == 3 ? launch_direct<2, 2, 4, true>(a, s) : launch_direct<2, 2, 4, false>(a, s);
         case CONV_GENERIC_64: return p == PREC_F16 ? launch_t<f16, 4, 1, 2>(a, s) : launch_t<float, 4, 1, 2>(a, s);
         default: return p == PREC_F16 ? launch_t<f16, 2, 2, 4>(a, s) : launch_t<float, 2, 2, 4>(a, s);
     }
