@@ -60,17 +60,19 @@ def cpu_baseline(mosaic_host, grid, names_w, budget_s=22.0, max_tiles=32, budget
                 break
         return done, time.time() - t0
     run(sample[:1], 60.0)                                  # untimed first tile (thread pool / allocator warm-up)
-    done, dt = run(sample, budget_s)
-    out = {"value": done / dt, "unit": "tiles/s", "cores": cores, "kind": "port",
-           "sample": "%d full 512x512 tiles of the S16k grid (tids %d..), sequential batch 1, zscale+minmax + torch-CPU "
-                     "fp32 yolov8l + NMS + IoU merge, %.1f s" % (done, sample[0], dt)}
-    if cores > 8:                                          # also report the 8-thread figure
-        torch.set_num_threads(8)
-        d8, t8 = run(sample, budget_8t_s)
-        torch.set_num_threads(cores)
-        out["value_8_threads"] = d8 / t8
-        out["sample_8_threads"] = "%d tiles, %.1f s" % (d8, t8)
-    return out
+    runs = []
+    for nthr, budget in ((cores, budget_s * 0.5), (8, budget_8t_s + budget_s * 0.5)):      # all cores, and 8 threads
+        if nthr > cores or any(r["threads"] == nthr for r in runs):
+            continue
+        torch.set_num_threads(nthr)
+        done, dt = run(sample, budget)
+        runs.append({"threads": nthr, "tiles_per_s": done / dt, "tiles": done, "seconds": dt})
+    torch.set_num_threads(cores)
+    best = max(runs, key=lambda r: r["tiles_per_s"])        # the better of the two is the baseline (more threads is not faster here)
+    return {"value": best["tiles_per_s"], "unit": "tiles/s", "cores": best["threads"], "kind": "port",
+            "sample": "%d full 512x512 tiles of the S16k grid (tids %d..), sequential batch 1, zscale+minmax + torch-CPU fp32 "
+                      "yolov8l + NMS + IoU merge, %.1f s with %d torch threads" % (best["tiles"], sample[0], best["seconds"], best["threads"]),
+            "runs": runs}
 
 
 def pmc_traffic(kernel_label):
@@ -80,9 +82,12 @@ def pmc_traffic(kernel_label):
 
     def family(n):
         n = n.replace(" ", "")
-        for fam in ("conv3x3_halo2_kernel", "conv3x3_halo_kernel", "conv3x3_pp_kernel", "conv3x3_c64_kernel", "stem_mfma_kernel"):
+        for fam in ("conv3x3_wide_kernel", "conv3x3_halo2_kernel", "conv3x3_halo_kernel", "conv3x3_pp_kernel", "conv3x3_c64_kernel",
+                    "stem_mfma_kernel"):
             if fam in n:
                 return fam
+        if "conv1x1_direct_kernel" in n:
+            return "conv1x1_direct_kernel<4" if ("<4,2" in n or "ILi4ELi2E" in n) else "conv1x1_direct_kernel<2"
         if "conv_igemm_kernel" in n:
             if "<4,2,4,3>" in n or "Li4ELi2ELi4ELi3E" in n:
                 return "conv_igemm_kernel<4,2,4,3>"

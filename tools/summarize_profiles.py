@@ -18,7 +18,7 @@ def pmc(dirname, counters):
     cnt = collections.Counter()
     if not f:
         return out, cnt
-    for r in csv.DictReader(open(f[0])):
+    for r in csv.DictReader(open(max(f, key=os.path.getmtime))):      # newest run if older ones are still around
         if r["Counter_Name"] in counters:
             k = short(r["Kernel_Name"])
             out[k][r["Counter_Name"]] += float(r["Counter_Value"])
@@ -28,6 +28,7 @@ def pmc(dirname, counters):
 
 
 stats = glob.glob(os.path.join(G, tag + "_ktrace", "*", "*kernel_stats.csv"))
+stats = [max(stats, key=os.path.getmtime)] if stats else []
 rows = list(csv.DictReader(open(stats[0]))) if stats else []
 with open(os.path.join(P, tag + "_final_kernel_stats.csv"), "w") as fp:
     if stats:
