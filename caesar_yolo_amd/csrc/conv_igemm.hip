@@ -1108,9 +1108,12 @@ static hipError_t launch_halo2(const ConvArgs& a, hipStream_t s) {
 // deep enough to request weights two stages ahead (counted vmcnt; halo pieces stay in flight for 2-3 stages).
 // 64-byte rows: chunk' = chunk ^ 2*((row>>2)&1) is conflict-free for the ds_read_b128 lane groups at any row offset.
 // Weights come from the second packed copy with 64-byte K chunks (ConvArgs::wgt32).
-template <bool TAIL>
+// WN = 1: the 64-channel variant (BN = 64): eight waves of 64 px x 64 ch (two image rows each), one DMA piece of weights
+// per wave and stage, 32 MFMAs per wave between barriers.
+template <bool TAIL, int WN>
 __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
-    constexpr int TH = 16, TW = 32, NW = 8, BN = 128, PWID = TW + 2;
+    constexpr int TH = 16, TW = 32, NW = 8, BN = 64 * WN, PWID = TW + 2;
+    constexpr int RPW = TH / (NW / WN), MIW = 2 * RPW, WPS = WN;          // image rows / pixel fragments per wave; weight pieces per wave and stage
     constexpr int PR = (TH + 2) * PWID, NPC = (PR + 15) / 16, PROUNDS = (NPC + NW - 1) / NW;
     constexpr int P_BYTES = PROUNDS * NW * 1024, SLAB = BN * 64, W_BYTES = 2 * SLAB, RING = 3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1119,7 +1122,7 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
     typedef __attribute__((address_space(3))) void lds_void;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
     const int H = a.Hi, W = a.Wi;
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     const int cpad = pad128(a.Cout);                      // packed weight rows (zero rows past Cout)
@@ -1146,8 +1149,8 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
         poff[j] = ok ? (unsigned)(((b * H + y) * W + x) * a.in0_ct + a.in0_coff + q * 8) * 2u : CY_OOB;
     }
     unsigned woff;
-    {
-        const int row = wave * 16 + (lane >> 2);
+    {   // WN = 2: every wave moves rows wave*16.. of BOTH taps of a stage; WN = 1: wave -> (tap wave>>2, rows (wave&3)*16..)
+        const int row = (WN == 2 ? wave : (wave & 3)) * 16 + (lane >> 2);
         woff = (unsigned)((n0 + row) * 64 + ((lane & 3) ^ (((row >> 2) & 1) << 1)) * 16);
     }
     auto dma_patch = [&](int buf, int slab) {               // slab: 32-channel slab index
@@ -1156,25 +1159,31 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_void*)(Pbuf + buf * P_BYTES + (j * NW + wave) * 1024), 16, poff[j], slab * 64, 0, 0);   // a lane survives it
     };
     auto dma_stage = [&](int ring, int slab0, int u0) {     // taps u0, u0+1 of the pair starting at slab slab0 (u in 0..17)
+        if constexpr (WN == 2) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int u = u0 + t, sl = slab0 + u / 9, tap = u % 9;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)(Wbuf + ring * W_BYTES + t * SLAB + wave * 1024), 16, woff, (sl * 9 + tap) * cpad * 64, 0, 0);
+            for (int t = 0; t < 2; ++t) {
+                const int u = u0 + t, sl = slab0 + u / 9, tap = u % 9;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)(Wbuf + ring * W_BYTES + t * SLAB + wave * 1024), 16, woff, (sl * 9 + tap) * cpad * 64, 0, 0);
+            }
+        } else {
+            const int t = wave >> 2, u = u0 + t, sl = slab0 + u / 9, tap = u % 9;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)(Wbuf + ring * W_BYTES + t * SLAB + (wave & 3) * 1024), 16, woff, (sl * 9 + tap) * cpad * 64, 0, 0);
         }
     };
-    f32x4 acc[4][8];
+    f32x4 acc[4][MIW];
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int mi = 0; mi < MIW; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fq = lane >> 4;
     // Fragment addresses = per-lane base + compile-time offset.  A halo row is r = wm*4*PWID + base + fr with `base`
     // known at compile time per (tap, mi) and wm*4*PWID = 0 mod 8, so the swizzle bit ((r>>2)&1) only depends on
     // base & 7 and the lane: eight lane bases cover every tap.  Weight rows are 0 mod 16 + fr: one lane base.
     unsigned pb[8];
+    const int rw0 = wm * RPW * PWID;                         // first halo row of this wave's pixels (0 mod 8 for WN = 2, 0 or 4 for WN = 1)
 #pragma unroll
     for (int c = 0; c < 8; ++c)
-        pb[c] = (unsigned)(wm * 4 * PWID * 64 + fr * 64 + ((fq ^ ((((c + fr) >> 2) & 1) << 1)) << 4));
+        pb[c] = (unsigned)(rw0 * 64 + fr * 64 + ((fq ^ ((((c + fr + (rw0 & 7)) >> 2) & 1) << 1)) << 4));
     const unsigned wl = (unsigned)(2 * P_BYTES + (wn * 64 + fr) * 64 + ((fq ^ (((fr >> 2) & 1) << 1)) << 4));
     // One stage = two taps = four half-steps of 16 MFMAs (4 channel blocks x 4 pixel fragments).  The fragment reads of
     // half-step h+1 are issued before the MFMAs of half-step h (register double buffer), and a scheduling fence after
@@ -1202,26 +1211,36 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
     auto stage_compute = [&](int st) {                       // taps u = 2*st, 2*st+1 of the current slab pair
         const int u0 = 2 * st, u1 = u0 + 1, t0 = u0 % 9, t1 = u1 % 9;
         const int p0 = (u0 / 9) * P_BYTES, p1 = (u1 / 9) * P_BYTES, w0 = (st % 3) * W_BYTES, w1 = w0 + SLAB;
-        load_w(wb[0], w0);
-        load_x(xa[0], p0, t0 / 3, t0 % 3, 0);
-        load_x(xa[1], p0, t0 / 3, t0 % 3, 1);
-        mma(wb[0], xa[0], 0);
-        __builtin_amdgcn_sched_barrier(0);
-        load_w(wb[1], w1);
-        load_x(xa[0], p1, t1 / 3, t1 % 3, 0);
-        mma(wb[0], xa[1], 1);
-        __builtin_amdgcn_sched_barrier(0);
-        load_x(xa[1], p1, t1 / 3, t1 % 3, 1);
-        mma(wb[1], xa[0], 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (!TAIL) mma(wb[1], xa[1], 1);                     // TAIL: the last 16 MFMAs are issued behind the stage barrier
+        if constexpr (WN == 2) {
+            load_w(wb[0], w0);
+            load_x(xa[0], p0, t0 / 3, t0 % 3, 0);
+            load_x(xa[1], p0, t0 / 3, t0 % 3, 1);
+            mma(wb[0], xa[0], 0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_w(wb[1], w1);
+            load_x(xa[0], p1, t1 / 3, t1 % 3, 0);
+            mma(wb[0], xa[1], 1);
+            __builtin_amdgcn_sched_barrier(0);
+            load_x(xa[1], p1, t1 / 3, t1 % 3, 1);
+            mma(wb[1], xa[0], 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!TAIL) mma(wb[1], xa[1], 1);                 // TAIL: the last 16 MFMAs are issued behind the stage barrier
+        } else {                                             // one half-step (4 fragments = this wave's 64 pixels) per tap
+            load_w(wb[0], w0);
+            load_x(xa[0], p0, t0 / 3, t0 % 3, 0);
+            load_w(wb[1], w1);
+            load_x(xa[1], p1, t1 / 3, t1 % 3, 0);
+            mma(wb[0], xa[0], 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!TAIL) mma(wb[1], xa[1], 0);
+        }
     };
 
     // prologue: halo of slab 0, weight stages 0 and 1
     dma_patch(0, 0);
     dma_stage(0, 0, 0);
     dma_stage(1, 0, 2);
-    CY_WAIT_VM(2);
+    CY_WAIT_VM(WPS);
     __builtin_amdgcn_s_barrier();
 #pragma unroll 1
     for (int cp = 0; cp < pairs; ++cp) {
@@ -1237,14 +1256,14 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
             stage_compute(st);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             // the weights of stage g+1 (requested first thing in stage g-1) must have landed; younger requests may fly on
-            if (st == 0 || st == 1) { CY_WAIT_VM(2 + PROUNDS); }
-            else if (st == 5 || st == 6) { if (more) { CY_WAIT_VM(2 + PROUNDS); } else { CY_WAIT_VM(2); } }
-            else if (has_w) { CY_WAIT_VM(2); }
+            if (st == 0 || st == 1) { CY_WAIT_VM(WPS + PROUNDS); }
+            else if (st == 5 || st == 6) { if (more) { CY_WAIT_VM(WPS + PROUNDS); } else { CY_WAIT_VM(WPS); } }
+            else if (has_w) { CY_WAIT_VM(WPS); }
             else { CY_WAIT_VM(0); }
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            if (TAIL) mma(wb[1], xa[1], 1);                  // operands are in registers: overlaps the next stage's DMA issue / first reads
+            if (TAIL) mma(wb[1], xa[1], WN == 2 ? 1 : 0);    // operands are in registers: overlaps the next stage's DMA issue / first reads
         }
     }
 
@@ -1253,8 +1272,8 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) bv[j] = a.bias[cbase + j];
 #pragma unroll
-    for (int mi = 0; mi < 8; ++mi) {
-        const int y = y0 + wm * 4 + (mi >> 1), x = x0 + (mi & 1) * 16 + fr;
+    for (int mi = 0; mi < MIW; ++mi) {
+        const int y = y0 + wm * RPW + (mi >> 1), x = x0 + (mi & 1) * 16 + fr;
         if (y >= H || x >= W) continue;
         const long pix = ((long)b * H + y) * W + x;
         float v[16];
@@ -1292,19 +1311,20 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
     }
 }
 
+template <int WN>
 static hipError_t launch_wide(const ConvArgs& a, hipStream_t s) {
-    constexpr int PR = 18 * 34, NPC = (PR + 15) / 16, PROUNDS = (NPC + 7) / 8;
-    const size_t lds = 2 * PROUNDS * 8 * 1024 + 3 * 2 * 128 * 64;
+    constexpr int PR = 18 * 34, NPC = (PR + 15) / 16, PROUNDS = (NPC + 7) / 8, BN = 64 * WN;
+    const size_t lds = 2 * PROUNDS * 8 * 1024 + 3 * 2 * BN * 64;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wide_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wide_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wide_kernel<false, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wide_kernel<true, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    const int blocks = a.B * ((a.Hi + 15) / 16) * ((a.Wi + 31) / 32) * ((pad64(a.Cout) + 127) / 128);
+    const int blocks = a.B * ((a.Hi + 15) / 16) * ((a.Wi + 31) / 32) * ((pad64(a.Cout) + BN - 1) / BN);
     static const int tail = getenv("CY_WIDE_TAIL") ? atoi(getenv("CY_WIDE_TAIL")) : 1;
-    if (tail) hipLaunchKernelGGL(conv3x3_wide_kernel<true>, dim3(blocks), dim3(512), lds, s, a);
-    else hipLaunchKernelGGL(conv3x3_wide_kernel<false>, dim3(blocks), dim3(512), lds, s, a);
+    if (tail) hipLaunchKernelGGL((conv3x3_wide_kernel<true, WN>), dim3(blocks), dim3(512), lds, s, a);
+    else hipLaunchKernelGGL((conv3x3_wide_kernel<false, WN>), dim3(blocks), dim3(512), lds, s, a);
     return hipGetLastError();
 }
 
@@ -1571,7 +1591,8 @@ static const char* const kVariantNames[CONV_NUM_VARIANTS] = {
     "conv3x3_pp_kernel<4> 3x3 s1 16x16px x128ch", "conv3x3_halo_kernel<4,*> 3x3 s1 16x16px x128ch",
     "conv3x3_c64_kernel 3x3 s1 64->64 persistent", "conv_igemm_kernel<4,2,4,3> generic 256x128, 3-slab ring",
     "conv3x3_wide_kernel 3x3 s1 16x32px x128ch, K slabs of 32",
-    "conv1x1_direct_kernel<4,2> 1x1 256px x256ch, pixels to regs", "conv1x1_direct_kernel<2,2> 1x1 256px x128ch, pixels to regs"};
+    "conv1x1_direct_kernel<4,2> 1x1 256px x256ch, pixels to regs", "conv1x1_direct_kernel<2,2> 1x1 256px x128ch, pixels to regs",
+    "conv3x3_wide_kernel<WN=1> 3x3 s1 16x32px x64ch"};
 const char* conv_variant_name(int v) { return v >= 0 && v < CONV_NUM_VARIANTS ? kVariantNames[v] : "?"; }
 
 static bool s2_direct() { static const int v = getenv("CY_S2_DIRECT") ? atoi(getenv("CY_S2_DIRECT")) : 1; return v != 0; }
@@ -1584,6 +1605,11 @@ int conv_variant(Precision p, const ConvArgs& a) {
     if (p == PREC_F16 && a.k == 3 && a.s == 1 && a.c1 == 0 && !a.up0 && !a.out_f32 && a.Cin % 64 == 0 &&
         a.out_bs == a.Ho * a.Wo && a.out_ro == 0) {
         static const int force = getenv("CY_HALO_WM") ? atoi(getenv("CY_HALO_WM")) : 0;     // tuning override
+        static const int wide64 = getenv("CY_WIDE64") ? atoi(getenv("CY_WIDE64")) : 1;
+        // 64-channel variant of the wide kernel for the box-head convs with deep inputs, when it fills the chip
+        if (narrow && wide64 && a.wgt32 && a.Cin >= 128 && a.Wi % 32 == 0 && force == 0 &&
+            (long)a.B * ((a.Hi + 15) / 16) * (a.Wi / 32) >= 256)
+            return CONV_WIDE_64;
         if (narrow && a.Cin == 64 && force != 8) return force == 9 ? CONV_GENERIC_64 : CONV_C64_PERSIST;
         if (narrow) return force == 9 ? CONV_GENERIC_64 : CONV_PP_64;
         if (force == 5) return CONV_PP_128;
@@ -1624,7 +1650,8 @@ hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s) {
             return v == 1 ? launch_halo<2, 3, 1>(b2, s) : launch_halo<2, 2>(b2, s);
         }
         case CONV_GENERIC_BIG: return launch_t<f16, 4, 2, 4, 3>(a, s);
-        case CONV_WIDE_128: return launch_wide(a, s);
+        case CONV_WIDE_128: return launch_wide<2>(a, s);
+        case CONV_WIDE_64: return launch_wide<1>(a, s);
         case CONV_DIRECT_256: return a.k == 3 ? launch_direct<4, 2, 3, true>(a, s) : launch_direct<4, 2, 3, false>(a, s);
         case CONV_DIRECT_128: return a.k == 3 ? launch_direct<2, 2, 4, true>(a, s) : launch_direct<2, 2, 4, false>(a, s);
         case CONV_GENERIC_64: return p == PREC_F16 ? launch_t<f16, 4, 1, 2>(a, s) : launch_t<float, 4, 1, 2>(a, s);

@@ -125,8 +125,8 @@ class HipDetector(object):
         self._chk(self.lib.cy_profile_enable(self.ctx, int(bool(on))))
 
     def profile_summary(self):
-        ent = (L.cy_prof_entry * 16)()
-        n = self._chk(self.lib.cy_profile_summary(self.ctx, ent, 16))
+        ent = (L.cy_prof_entry * 32)()
+        n = self._chk(self.lib.cy_profile_summary(self.ctx, ent, 32))
         return [dict(kernel=ent[i].kernel.decode(), ms=ent[i].ms, flops=ent[i].flops, launches=ent[i].launches) for i in range(n)]
 
     def profile_layers(self):
