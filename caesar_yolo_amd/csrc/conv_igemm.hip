@@ -307,8 +307,16 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_ige
                 for (int j4 = 0; j4 < 4; ++j4)
                     *reinterpret_cast<f32x4*>(dst + 4 * j4) = f32x4{v[4 * j4], v[4 * j4 + 1], v[4 * j4 + 2], v[4 * j4 + 3]};
             }
+        } else if (a.out_f32 && !a.res && cbase + 16 <= a.Cout) {
+            // fp32 head output (box logits): rows of the prediction buffer are 64+nc floats, so only dword-aligned; four
+            // 16-byte stores per lane through a 4-byte-aligned vector type instead of sixteen scattered dword stores
+            typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+            float* dst = reinterpret_cast<float*>(a.out) + opix * a.out_ct + a.out_coff + cbase;
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4)
+                *reinterpret_cast<f32x4u*>(dst + 4 * j4) = f32x4u{v[4 * j4], v[4 * j4 + 1], v[4 * j4 + 2], v[4 * j4 + 3]};
         } else {
-            // ragged channel count or fp32 head output: scalar stores (detect-head 1x1 convs only)
+            // ragged channel count (class logits, nc channels): scalar stores
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int c = cbase + j;
