@@ -62,13 +62,23 @@ std::vector<std::vector<int>> neighbor_lists(const int* tiles, int T, const std:
     }
     return nb;
 }
+// Both entry points run on the same grid, once per mosaic pass: the lists are computed for every tile once and kept while
+// the tile array is unchanged (compared by value, 16 bytes per tile).
+const std::vector<std::vector<int>>& cached_neighbor_lists(const int* tiles, int T) {
+    static thread_local std::vector<int> key;
+    static thread_local std::vector<std::vector<int>> lists;
+    if ((int)key.size() != 4 * T || !std::equal(key.begin(), key.end(), tiles)) {
+        lists = neighbor_lists(tiles, T, std::vector<char>(T, 1));
+        key.assign(tiles, tiles + 4 * (size_t)T);
+    }
+    return lists;
+}
 }  // namespace
 
 extern "C" int cy_make_tile_records(const float* det, const int* det_tile, int n, const int* tiles, int T, double* rec) {
     if (n < 0 || T < 1 || (n > 0 && (!det || !det_tile || !rec)) || !tiles) return CY_ERR_ARG;
-    std::vector<char> need(T, 0);
-    for (int i = 0; i < n; ++i) { if (det_tile[i] < 0 || det_tile[i] >= T) return CY_ERR_ARG; need[det_tile[i]] = 1; }
-    const auto nb = neighbor_lists(tiles, T, need);
+    for (int i = 0; i < n; ++i) if (det_tile[i] < 0 || det_tile[i] >= T) return CY_ERR_ARG;
+    const auto& nb = cached_neighbor_lists(tiles, T);
     for (int i = 0; i < n; ++i) {
         const int t = det_tile[i];
         const int* tc = tiles + 4 * t;
@@ -109,11 +119,10 @@ extern "C" int cy_merge_edge_sources(const double* rec, int n, const int* tiles,
     if (N == 0) return nout;
     // sources of each tile (positions in tbm are ascending because records are grouped by ascending tile): CSR
     std::vector<int> tstart(T + 1, 0);
-    std::vector<char> need(T, 0);
-    for (int k = 0; k < N; ++k) { const int t = (int)rec[8 * tbm[k] + 6]; if (t < 0 || t >= T) return CY_ERR_ARG; tstart[t + 1]++; need[t] = 1; }
+    for (int k = 0; k < N; ++k) { const int t = (int)rec[8 * tbm[k] + 6]; if (t < 0 || t >= T) return CY_ERR_ARG; tstart[t + 1]++; }
     for (int t = 0; t < T; ++t) tstart[t + 1] += tstart[t];
     for (int k = 1; k < N; ++k) if (rec[8 * tbm[k] + 6] < rec[8 * tbm[k - 1] + 6]) return CY_ERR_ARG;   // must be tile-ordered
-    const auto nb = neighbor_lists(tiles, T, need);
+    const auto& nb = cached_neighbor_lists(tiles, T);
     // overlapping pairs (i < j) between sources of neighbouring tiles, generated in lexicographic order, so the CSR rows
     // below come out ascending == the reference's adjacency insertion order (i asc, then j asc)
     std::vector<std::pair<int, int>> pairs;
@@ -127,6 +136,10 @@ extern "C" int cy_merge_edge_sources(const double* rec, int n, const int* tiles,
         const int ti = tof[i];
         for (int tj : nb[ti]) {                   // tid_j in neighborTileIds(tile_i): a tile is never its own neighbour
             if (tj < ti) continue;                // j > i implies tile_j >= tile_i
+            // a source lies inside its tile's inclusive bounds (cy_make_tile_records), so a box that misses tile tj misses
+            // every source of tile tj: skips most of the eight neighbours without touching their sources
+            const int* q = tiles + 4 * tj;
+            if (ax2 < q[0] || ax1 > q[1] || ay2 < q[2] || ay1 > q[3]) continue;
             for (int j = tstart[tj]; j < tstart[tj + 1]; ++j) {
                 if (j <= i) continue;
                 const double* b = &box[4 * j];

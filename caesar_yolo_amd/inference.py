@@ -160,7 +160,9 @@ class TileEngine(object):
         det_h = np.ascontiguousarray(det.cpu().numpy(), np.float32)
         dtile_h = np.ascontiguousarray(dtile.cpu().numpy().astype(np.int32))
         t1 = _t.time()
-        out = merge_records(det_h, dtile_h, self.grid)
+        if getattr(self, "_tiles_np", None) is None:              # the grid as the C-ABI wants it, converted once
+            self._tiles_np = np.ascontiguousarray(np.array(self.grid, np.int32).reshape(-1, 4))
+        out = merge_records(det_h, dtile_h, self._tiles_np)
         stats["merge_host_ms"] = 1e3 * (_t.time() - t1)
         stats["merge_d2h_ms"] = 1e3 * (t1 - t0)
         return out, stats
@@ -176,7 +178,7 @@ def merge_records(det, dtile, grid):
     n = det.shape[0]
     if n == 0:
         return np.zeros((0, 8), np.float64)
-    tiles = np.ascontiguousarray(np.array(grid, np.int32).reshape(-1, 4))
+    tiles = grid if isinstance(grid, np.ndarray) else np.ascontiguousarray(np.array(grid, np.int32).reshape(-1, 4))
     T = tiles.shape[0]
     lib = L.load()
     ip, fp, dp = C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_double)
