@@ -821,30 +821,52 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const ConvArgs a) {
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // 18 groups (tap, kk) of 8 fragment reads + 16 MFMAs.  With ONE wave per SIMD nothing else hides the LDS latency,
+        // so the fragments are double-buffered in registers: group g+1 is read before the MFMAs of group g are issued
+        // (fences keep that order; the workgroup has 512 VGPRs per lane to spend).
+        f16x8 xa[2][4], wb[2][NI];
+        auto load_group = [&](int g, f16x8* x, f16x8* w) {
+            const int tap = g >> 1, kk = g & 1, kh = tap / 3, kw = tap - kh * 3, qf = fq + 4 * kk;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int kh = tap / 3, kw = tap - kh * 3;
+            for (int mi = 0; mi < 4; ++mi) {
+                const int r = (wm * 4 + mi + kh) * (TW + 2) + kw + fr;
+                x[mi] = *reinterpret_cast<const f16x8*>(P + r * 128 + ((qf ^ (r & 7)) << 4));
+            }
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const int qf = fq + 4 * kk;
-                f16x8 xa[4], wb[NI];
+            for (int ni = 0; ni < NI; ++ni)
+                w[ni] = *reinterpret_cast<const f16x8*>(Wl + (tap * 64 + ni * 16 + fr) * 128 + ((qf ^ (fr & 7)) << 4));
+        };
+        // residual of this patch: requested now, used in the epilogue (its latency hides under the 288 MFMAs)
+        const int tx = pidx % tiles_x, ty = (pidx / tiles_x) % tiles_y, b = pidx / (tiles_x * tiles_y);
+        f16x8 rres[4][2];
+        if (a.res && cbase + 16 <= a.Cout) {
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi) {
-                    const int r = (wm * 4 + mi + kh) * (TW + 2) + kw + fr;
-                    xa[mi] = *reinterpret_cast<const f16x8*>(P + r * 128 + ((qf ^ (r & 7)) << 4));
-                }
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-                    wb[ni] = *reinterpret_cast<const f16x8*>(Wl + (tap * 64 + ni * 16 + fr) * 128 + ((qf ^ (fr & 7)) << 4));
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                    for (int mi = 0; mi < 4; ++mi)
-                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0);
+            for (int mi = 0; mi < 4; ++mi) {
+                const int y = ty * TH + wm * 4 + mi, x = tx * TW + fr;
+                const bool ok = y < H && x < W;
+                const long pix = ok ? ((long)b * H + y) * W + x : 0;      // masked lanes read pixel 0 (valid memory), never used
+                const f16* rp = reinterpret_cast<const f16*>(a.res) + pix * a.res_ct + a.res_coff + cbase;
+                rres[mi][0] = *reinterpret_cast<const f16x8*>(rp);
+                rres[mi][1] = *reinterpret_cast<const f16x8*>(rp + 8);
             }
         }
+        load_group(0, xa[0], wb[0]);
+#pragma unroll
+        for (int g = 0; g < 18; ++g) {
+            if (g + 1 < 18) load_group(g + 1, xa[(g + 1) & 1], wb[(g + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[g & 1][ni], xa[g & 1][mi], acc[ni][mi], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // the next halo (requested before this patch's MFMAs) has landed by now; waiting for it HERE, before the stores of the
+        // epilogue are issued, keeps those stores out of the wait: they retire under the next patch's MFMAs
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        CY_WAIT_VM(0);
         // ---- epilogue of this patch
-        const int tx = pidx % tiles_x, ty = (pidx / tiles_x) % tiles_y, b = pidx / (tiles_x * tiles_y);
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
             const int y = ty * TH + wm * 4 + mi, x = tx * TW + fr;
@@ -862,10 +884,8 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const ConvArgs a) {
             if (cbase + 16 <= a.Cout) {
                 f16* dst = reinterpret_cast<f16*>(a.out) + pix * a.out_ct + a.out_coff + cbase;
                 if (a.res) {
-                    const f16* rp = reinterpret_cast<const f16*>(a.res) + pix * a.res_ct + a.res_coff + cbase;
-                    const f16x8 r0v = *reinterpret_cast<const f16x8*>(rp), r1v = *reinterpret_cast<const f16x8*>(rp + 8);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) { v[j] += (float)r0v[j]; v[8 + j] += (float)r1v[j]; }
+                    for (int j = 0; j < 8; ++j) { v[j] += (float)rres[mi][0][j]; v[8 + j] += (float)rres[mi][1][j]; }
                 }
                 f16x8 o0, o1;
 #pragma unroll
@@ -883,10 +903,8 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const ConvArgs a) {
                 }
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        CY_WAIT_VM(0);                                       // next halo landed (and this patch's stores retired)
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();                        // every wave is done reading this patch's halo; the landed one is published
     }
 }
 
