@@ -1789,12 +1789,22 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemArgs a, const 
     }
     const long ngroups = ((long)a.B * a.Ho * a.Wo + 15) / 16;
     const long npix = (long)a.B * a.Ho * a.Wo;
-    const long wave_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+    const int wave_id = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = gridDim.x * 4;
     const f16* in = reinterpret_cast<const f16*>(a.in);
-    for (long g = wave_id; g < ngroups; g += nwaves) {
-        const long pix = g * 16 + fr;
+    const bool rows16 = (a.Wo & 15) == 0;                   // a group of 16 pixels never straddles an image row: the
+    const int gw = a.Wo >> 4;                               // (b, ho, wo) split is wave-uniform -> scalar divisions
+    for (int g = wave_id; g < (int)ngroups; g += nwaves) {
+        const long pix = (long)g * 16 + fr;
         const bool pv = pix < npix;
-        const int wo = (int)(pix % a.Wo), ho = (int)((pix / a.Wo) % a.Ho), b = (int)(pix / ((long)a.Wo * a.Ho));
+        int wo, ho, b;
+        if (rows16) {
+            const int row = g / gw;                          // = b*Ho + ho (uniform)
+            wo = (g - row * gw) * 16 + fr;
+            b = row / a.Ho;
+            ho = row - b * a.Ho;
+        } else {
+            wo = (int)(pix % a.Wo); ho = (int)((pix / a.Wo) % a.Ho); b = (int)(pix / ((long)a.Wo * a.Ho));
+        }
         f16x8 xa;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
