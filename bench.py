@@ -111,7 +111,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=16384, help="mosaic edge (default: the 16k config)")
-    ap.add_argument("--batch", type=int, default=192)
+    ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-launch hipEvents in the timed region")
     args = ap.parse_args()

@@ -38,34 +38,78 @@ def shard(items, rank, world):
     return items[lo:hi]
 
 
-def partition_tiles(grid, imgsz, world):
+# Cost model of one rank's pass, in units of "one full-size tile": a batch of n tiles of relative letterboxed area w costs
+# n*w plus a fixed launch/pipeline overhead per batch (measured on MI355X at world 8: 198 full tiles in one batch 28.7 ms,
+# in two 30.5 ms, in three 36.6 ms; full rate 7285 tiles/s -> 12-25 tile-equivalents per batch; small batches of
+# ragged tiles run well below the full rate).
+BATCH_OVERHEAD_TILES = 20.0
+
+
+def _rank_cost(segments, cost, batch):
+    """segments: list of (shape, n tiles).  Estimated pass time in tile-equivalents."""
+    t = 0.0
+    for shp, n in segments:
+        if n:
+            t += n * cost[shp] + BATCH_OVERHEAD_TILES * ((n + batch - 1) // batch)
+    return t
+
+
+def partition_tiles(grid, imgsz, world, batch=256):
     """Deterministic cost-balanced tile -> rank assignment (every rank computes the same one).
 
     Tiles are grouped by shape (one kernel-launch sequence per shape), shapes ordered by letterboxed area (largest
-    first), the concatenated list is cut into `world` contiguous runs of equal cost (cost = letterboxed pixels).  A rank
-    therefore sees at most a couple of shape classes and few, large batches -- with plain per-class round-robin every
-    rank would get a sliver of each ragged class and pay a ~100-launch sequence for a handful of tiles.
+    first), and the concatenated list is cut into `world` contiguous runs of (nearly) equal ESTIMATED TIME, where the
+    estimate charges every batch a fixed overhead on top of its pixels: the rank that inherits the three small ragged
+    classes of a grid pays three extra launch sequences and therefore gets fewer full tiles.  The cut is the greedy
+    packing for the smallest feasible time bound (bisection), so a rank still sees at most a couple of shape classes.
     Returns per rank: list of ((th, tw), [tile ids])."""
     classes = {}
     for tid, (x0, x1, y0, y1) in enumerate(grid):
         classes.setdefault((y1 - y0, x1 - x0), []).append(tid)
-    cost = {}
+    area = {}
     for (th, tw) in classes:
         lb = L.letterbox(th, tw, imgsz)
-        cost[(th, tw)] = lb.H * lb.W
-    order = sorted(classes, key=lambda k: (-cost[k], -k[0], -k[1]))
+        area[(th, tw)] = lb.H * lb.W
+    amax = float(max(area.values())) if area else 1.0
+    cost = {k: v / amax for k, v in area.items()}
+    order = sorted(classes, key=lambda k: (-area[k], -k[0], -k[1]))
     seq = [(shp, t) for shp in order for t in classes[shp]]
-    total = float(sum(cost[shp] for shp, _ in seq))
-    out = [[] for _ in range(world)]
-    acc, r = 0.0, 0
-    for shp, t in seq:
-        while r < world - 1 and acc >= total * (r + 1) / world:          # half-open runs: [total*r/world, total*(r+1)/world)
-            r += 1
-        if not out[r] or out[r][-1][0] != shp:
-            out[r].append((shp, []))
-        out[r][-1][1].append(t)
-        acc += cost[shp]
-    return out
+
+    def pack(bound):
+        """Greedy contiguous packing: a rank takes tiles while its estimated time stays <= bound."""
+        out, cur, segs = [], [], []
+        for shp, t in seq:
+            trial = list(segs)
+            if trial and trial[-1][0] == shp:
+                trial[-1] = (shp, trial[-1][1] + 1)
+            else:
+                trial.append((shp, 1))
+            if cur and _rank_cost(trial, cost, batch) > bound and len(out) < world - 1:
+                out.append(cur)
+                cur, segs = [], []
+                trial = [(shp, 1)]
+            segs = trial
+            if not cur or cur[-1][0] != shp:
+                cur.append((shp, []))
+            cur[-1][1].append(t)
+        out.append(cur)
+        while len(out) < world:
+            out.append([])
+        return out
+
+    def worst(parts):
+        return max(_rank_cost([(shp, len(t)) for shp, t in p], cost, batch) for p in parts)
+    if world <= 1 or not seq:
+        return pack(float("inf"))[:1] + [[] for _ in range(max(world - 1, 0))]
+    total = _rank_cost([(shp, len(classes[shp])) for shp in order], cost, batch)
+    lo, hi = total / world * 0.5, total + BATCH_OVERHEAD_TILES * world
+    for _ in range(40):                                     # bisection on the time bound; pack() is monotone in it
+        mid = 0.5 * (lo + hi)
+        if worst(pack(mid)) <= mid:
+            hi = mid
+        else:
+            lo = mid
+    return pack(hi)
 
 
 class TileEngine(object):
@@ -76,7 +120,7 @@ class TileEngine(object):
         self.pre_cfg, self.imgsz = pre_cfg, int(imgsz)
         self.conf, self.iou, self.soft, self.hard = float(conf), float(iou), float(soft), float(hard)
         self.rank, self.world, self.batch = rank, world, min(int(batch), detector.max_batch)
-        parts = partition_tiles(self.grid, self.imgsz, world)
+        parts = partition_tiles(self.grid, self.imgsz, world, self.batch)
         self.counts = [sum(len(t) for _, t in p) for p in parts]
         self.cap_tiles = max(max(self.counts), 1)
         self.my = parts[rank]

@@ -1,0 +1,34 @@
+"""Time every rank's LOCAL share of the S16k grid at a given world size, one after the other on one GPU (developer tool):
+the N-GPU step time is max over ranks of this + gather + cross-tile merge.  python tools/emulate_ranks.py [world] [batch]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import __graft_entry__ as ge
+ge.build()
+from caesar_yolo_amd import synth, utils, preprocessing as PP
+from caesar_yolo_amd.model import YOLO
+from caesar_yolo_amd.inference import TileEngine
+world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+batch = int(sys.argv[2]) if len(sys.argv) > 2 else 192
+size = int(sys.argv[3]) if len(sys.argv) > 3 else 16384
+m = YOLO("seeded:l:5", precision="fp16", max_batch=batch, max_imgsz=512, device=0)
+det = m.engine(0)
+mos = det.mosaic_to_device(synth.make_mosaic(size, seed=20260104))
+grid = utils.generate_tiles(0, size - 1, 0, size - 1, 512, 512, 0.8, 0.8)
+cfg = PP.DataPreprocessor([PP.ZScaleTransformer([0.25] * 3), PP.MinMaxNormalizer(0, 255)]).program()
+worst = 0.0
+for r in range(world):
+    eng = TileEngine(det, mos, grid, cfg, 512, 0.7, 0.5, 0.3, 0.8, r, world, batch)
+    for _ in range(2):
+        eng.run_local()
+    torch.cuda.synchronize()
+    reps = 5
+    t = time.time()
+    for _ in range(reps):
+        eng.run_local()
+        torch.cuda.synchronize()
+    dt = (time.time() - t) / reps
+    worst = max(worst, dt)
+    print("rank %d: %4d tiles, batches %s: %.2f ms (%.0f tiles/s)" % (r, eng.n_my, [(p[0], p[1], p[2]) for p in eng.plan], dt * 1e3, eng.n_my / dt))
+print("max over ranks %.2f ms -> %.0f tiles/s for %d tiles before gather+merge" % (worst * 1e3, len(grid) / worst, len(grid)))
