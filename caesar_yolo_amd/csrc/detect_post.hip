@@ -77,7 +77,7 @@ hipError_t launch_decode(const DecodeArgs& a, hipStream_t s) {
 // keys -- in LDS when they fit, else through L2; (2) wave 0 scans the ordered list 64 boxes at a time: every lane tests
 // its box against the boxes kept so far (<= 300, in LDS), then the 64 survivors are resolved against each other in
 // order with ballots; the scan stops at max_det kept boxes, which are exactly torchvision's keep[:max_det].
-constexpr int NMS_LDS_KEYS = 4096;
+constexpr int NMS_LDS_KEYS = 8192;     // sort keys held in (dynamic) LDS: 64 KiB; more candidates than this sort in global memory
 
 __device__ __forceinline__ bool iou_gt(float ix1, float iy1, float ix2, float iy2, float iarea,
                                        float jx1, float jy1, float jx2, float jy2, float jarea, float thr) {
@@ -89,7 +89,7 @@ __device__ __forceinline__ bool iou_gt(float ix1, float iy1, float ix2, float iy
 }
 
 __global__ __launch_bounds__(256) void nms_kernel(const NmsArgs a, int cap_pow2) {
-    __shared__ uint64_t lkeys[NMS_LDS_KEYS];
+    extern __shared__ __attribute__((aligned(16))) uint64_t lkeys[];      // NMS_LDS_KEYS entries (launch_nms)
     __shared__ float kx1[MAXDET], ky1[MAXDET], kx2[MAXDET], ky2[MAXDET], kar[MAXDET];
     __shared__ int kslot[MAXDET];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -123,8 +123,15 @@ __global__ __launch_bounds__(256) void nms_kernel(const NmsArgs a, int cap_pow2)
             __syncthreads();
         }
     if (n > MAX_NMS) n = MAX_NMS;
-    if (tid >= 64) return;                              // the scan is one wavefront
-    const int lane = tid;
+    // ---- scan in score order, 64 candidates per round.  The test of a round's candidates against the boxes kept so far is
+    // split over the four waves (wave w takes kept boxes w, w+4, ...: the dense tiles that set this kernel's duration have
+    // thousands of candidates against up to 300 kept boxes); wave 0 then resolves the round's survivors among themselves
+    // in order, exactly as a one-wave scan would.
+    __shared__ unsigned long long amask[4];
+    __shared__ int s_nk;
+    const int lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_nk = 0;
+    __syncthreads();
     int nk = 0;
     for (int base = 0; base < n && nk < a.max_det; base += 64) {
         const int idx = base + lane;
@@ -139,28 +146,45 @@ __global__ __launch_bounds__(256) void nms_kernel(const NmsArgs a, int cap_pow2)
             area = (x2 - x1) * (y2 - y1);
         }
         bool alive = valid;
-        for (int t = 0; t < nk; ++t) {
-            if (alive && iou_gt(kx1[t], ky1[t], kx2[t], ky2[t], kar[t], x1, y1, x2, y2, area, a.iou)) alive = false;
-            if ((t & 15) == 15 && __ballot(alive) == 0ull) break;
+        for (int t = wave; t < nk; t += 16) {                // four kept boxes per trip: their LDS reads are in flight together
+            float qx1[4], qy1[4], qx2[4], qy2[4], qar[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int tt = t + 4 * q;
+                const bool in = tt < nk;                     // past the list: an empty box (intersection 0 -> never suppresses)
+                qx1[q] = in ? kx1[tt] : 0.0f; qy1[q] = in ? ky1[tt] : 0.0f; qx2[q] = in ? kx2[tt] : 0.0f; qy2[q] = in ? ky2[tt] : 0.0f;
+                qar[q] = in ? kar[tt] : 0.0f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (alive && iou_gt(qx1[q], qy1[q], qx2[q], qy2[q], qar[q], x1, y1, x2, y2, area, a.iou)) alive = false;
+            if (__ballot(alive) == 0ull) break;
         }
-        unsigned long long m = __ballot(alive);
-        while (m != 0ull && nk < a.max_det) {
-            const int j = __ffsll((long long)m) - 1;    // lowest alive lane = next kept box (wave-uniform)
-            const float jx1 = __shfl(x1, j), jy1 = __shfl(y1, j), jx2 = __shfl(x2, j), jy2 = __shfl(y2, j);
-            const float jar = __shfl(area, j);
-            const int jslot = __shfl(slot, j);
-            if (lane == 0) { kx1[nk] = jx1; ky1[nk] = jy1; kx2[nk] = jx2; ky2[nk] = jy2; kar[nk] = jar; kslot[nk] = jslot; }
-            ++nk;
-            if (lane > j && alive && iou_gt(jx1, jy1, jx2, jy2, jar, x1, y1, x2, y2, area, a.iou)) alive = false;
-            if (lane == j) alive = false;
-            m = __ballot(alive);
+        const unsigned long long mw = __ballot(alive);
+        if (lane == 0) amask[wave] = mw;
+        __syncthreads();
+        if (wave == 0) {
+            unsigned long long m = amask[0] & amask[1] & amask[2] & amask[3];
+            alive = (m >> lane) & 1ull;
+            while (m != 0ull && nk < a.max_det) {
+                const int j = __ffsll((long long)m) - 1;    // lowest alive lane = next kept box (wave-uniform)
+                const float jx1 = __shfl(x1, j), jy1 = __shfl(y1, j), jx2 = __shfl(x2, j), jy2 = __shfl(y2, j);
+                const float jar = __shfl(area, j);
+                const int jslot = __shfl(slot, j);
+                if (lane == 0) { kx1[nk] = jx1; ky1[nk] = jy1; kx2[nk] = jx2; ky2[nk] = jy2; kar[nk] = jar; kslot[nk] = jslot; }
+                ++nk;
+                if (lane > j && alive && iou_gt(jx1, jy1, jx2, jy2, jar, x1, y1, x2, y2, area, a.iou)) alive = false;
+                if (lane == j) alive = false;
+                m = __ballot(alive);
+            }
+            if (lane == 0) s_nk = nk;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_s_waitcnt(0xc07f);             // lgkmcnt(0): kept[] stores visible to the next round's reads
+        __syncthreads();                                // kept[] and the count are visible to every wave's next round
+        nk = s_nk;
     }
     // ---- emit: undo the letterbox (scale_boxes + clip_boxes) on the un-offset boxes, in kept (= score) order
-    if (lane == 0) a.det_count[b] = nk;
-    for (int t = lane; t < nk; t += 64) {
+    if (tid == 0) a.det_count[b] = nk;
+    for (int t = tid; t < nk; t += 256) {
         const float* c = cand + kslot[t] * 6;
         float bx1 = (c[0] - (float)a.padw) / a.gain, by1 = (c[1] - (float)a.padh) / a.gain;
         float bx2 = (c[2] - (float)a.padw) / a.gain, by2 = (c[3] - (float)a.padh) / a.gain;
@@ -176,15 +200,22 @@ hipError_t launch_nms(const NmsArgs& a, hipStream_t s) {
     if (a.max_det > MAXDET) return hipErrorInvalidValue;
     int cp2 = 1;
     while (cp2 < a.cap) cp2 <<= 1;
-    hipLaunchKernelGGL(nms_kernel, dim3(a.B), dim3(256), 0, s, a, cp2);
+    static bool attr_set = false;
+    const size_t lds = (size_t)NMS_LDS_KEYS * sizeof(uint64_t);
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds + 16384);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(nms_kernel, dim3(a.B), dim3(256), lds, s, a, cp2);
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------ IoU graph merge
-// One wavefront per tile, N <= 300 detections.  Pair tests are lane-parallel (one ballot fills 64 adjacency bits);
-// connected components are walked by lane 0 in exactly the reference's DFS preorder, because the survivor of a
-// component is the FIRST member in that order with the strictly largest score (evaluation.py:322-331).
-__global__ __launch_bounds__(64) void iou_merge_kernel(const MergeArgs a) {
+// One workgroup (four waves) per tile, N <= 300 detections.  Pair tests are lane-parallel (one ballot fills 64 adjacency
+// bits) and row-parallel over the waves (LDS atomic OR); connected components are walked by thread 0 in exactly the
+// reference's DFS preorder, because the survivor of a component is the FIRST member in that order with the strictly
+// largest score (evaluation.py:322-331).
+__global__ __launch_bounds__(256) void iou_merge_kernel(const MergeArgs a) {
     constexpr int W64 = (MAXDET + 63) / 64;
     __shared__ int sel[MAXDET];
     __shared__ float bx[MAXDET][4];
@@ -192,13 +223,15 @@ __global__ __launch_bounds__(64) void iou_merge_kernel(const MergeArgs a) {
     __shared__ int cl[MAXDET];
     __shared__ unsigned long long adj[MAXDET][W64];
     __shared__ int stack[MAXDET];
-    const int b = blockIdx.x, lane = threadIdx.x;
+    __shared__ int s_n, s_nerr;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int nin = a.det_count[b];
     if (nin > a.max_det) nin = a.max_det;
     const float* det = a.det + (size_t)b * a.max_det * 6;
     // ---- score re-filter (evaluation.py:282 drops score < thr), order preserved; degenerate boxes are dropped and
     // counted (the reference would abort on get_iou's assert)
     int n = 0, nerr = 0;
+    if (wave == 0) {
     for (int base = 0; base < nin; base += 64) {
         const int i = base + lane;
         bool keep = false, bad = false;
@@ -218,10 +251,14 @@ __global__ __launch_bounds__(64) void iou_merge_kernel(const MergeArgs a) {
         }
         n += __popcll(m);
     }
-    for (int i = lane; i < n * W64; i += 64) adj[i / W64][i % W64] = 0ull;
+    if (lane == 0) { s_n = n; s_nerr = nerr; }
+    }
+    __syncthreads();
+    n = s_n; nerr = s_nerr;
+    for (int i = tid; i < n * W64; i += 256) adj[i / W64][i % W64] = 0ull;
     __syncthreads();
     // ---- adjacency: mergeable = iou >= hard or (same class and iou >= soft); iou = f32 areas, f64 division
-    for (int i = 0; i < n - 1; ++i) {
+    for (int i = wave; i < n - 1; i += 4) {                 // rows are independent: one per wave at a time
         const float ax1 = bx[i][0], ay1 = bx[i][1], ax2 = bx[i][2], ay2 = bx[i][3];
         const float aarea = (ax2 - ax1) * (ay2 - ay1);
         const int acl = cl[i];
@@ -239,16 +276,15 @@ __global__ __launch_bounds__(64) void iou_merge_kernel(const MergeArgs a) {
                     iou = (double)inter / (double)uni;
                 }
                 e = (iou >= a.hard) || (acl == cl[j] && iou >= a.soft);
-                if (e) adj[j][i >> 6] |= 1ull << (i & 63);      // row j is owned by this lane in this round
+                if (e) atomicOr(&adj[j][i >> 6], 1ull << (i & 63));      // other waves may be setting other bits of this word
             }
             const unsigned long long m = __ballot(e);
-            if (lane == 0 && m) adj[i][w] |= m;
+            if (lane == 0 && m) atomicOr(&adj[i][w], m);
         }
-        __syncthreads();
     }
     __syncthreads();
     // ---- connected components in DFS preorder (graph.py:9-41), survivor = first strict maximum of the score
-    if (lane == 0) {
+    if (tid == 0) {
         unsigned long long vis[W64];
         for (int w = 0; w < W64; ++w) vis[w] = 0ull;
         int nout = 0;
@@ -264,9 +300,13 @@ __global__ __launch_bounds__(64) void iou_merge_kernel(const MergeArgs a) {
             while (sp > 0) {
                 const int v = stack[sp - 1];
                 int u = -1;
-                for (int w = 0; w < W64 && u < 0; ++w) {
-                    const unsigned long long c = adj[v][w] & ~vis[w];
-                    if (c) u = w * 64 + __ffsll((long long)c) - 1;
+                unsigned long long row[W64];
+#pragma unroll
+                for (int w = 0; w < W64; ++w) row[w] = adj[v][w];          // all words in flight at once: one LDS latency per step
+#pragma unroll
+                for (int w = 0; w < W64; ++w) {
+                    const unsigned long long c = row[w] & ~vis[w];
+                    if (c && u < 0) u = w * 64 + __ffsll((long long)c) - 1;
                 }
                 if (u < 0) { --sp; continue; }
                 vis[u >> 6] |= 1ull << (u & 63);
@@ -287,7 +327,7 @@ __global__ __launch_bounds__(64) void iou_merge_kernel(const MergeArgs a) {
 
 hipError_t launch_iou_merge(const MergeArgs& a, hipStream_t s) {
     if (a.max_det > MAXDET) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(iou_merge_kernel, dim3(a.B), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(iou_merge_kernel, dim3(a.B), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
