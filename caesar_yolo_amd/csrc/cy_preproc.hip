@@ -138,6 +138,26 @@ __device__ __forceinline__ bool in_set(const ClipSet& cs, const TileView& tv, in
     return v >= cs.L && v <= cs.U;
 }
 
+// Histogram increment with wave-level aggregation.  Radio-map pixels are mostly background noise of one sign and exponent,
+// so in the leading radix passes (and in the 256-bin equalisation histogram) almost every lane of a wave hits the SAME bin:
+// plain LDS atomics serialise on that address (measured: 13 ms per 96-tile batch of the 3-channel 640^2 pipeline).  Up to
+// three rounds of "count the lanes that share the first pending lane's bin, one atomic for all of them" take care of the
+// concentrated case; whatever is still pending afterwards (uniformly spread low bits) goes through ordinary atomics.
+__device__ __forceinline__ void hist_add(unsigned* hist, unsigned bin, bool active) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(active);
+#pragma unroll 1
+    for (int it = 0; it < 3 && todo != 0ull; ++it) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const unsigned lb = (unsigned)__shfl((int)bin, leader);
+        const unsigned long long same = __ballot(active && bin == lb);
+        if (lane == leader) atomicAdd(&hist[lb], (unsigned)__popcll(same));
+        if ((same >> lane) & 1ull) active = false;
+        todo &= ~same;
+    }
+    if (active) atomicAdd(&hist[bin], 1u);
+}
+
 // exact k-th smallest (0-based) of the set, as a key; 6 passes of 11/11/11/11/11/9 bits
 __device__ unsigned long long radix_select(Smem& s, const TileView& tv, const PreProgram& pg, int upto, const double* params,
                                            const double* heq, const ClipSet& cs, unsigned long long k) {
@@ -148,12 +168,20 @@ __device__ unsigned long long radix_select(Smem& s, const TileView& tv, const Pr
         const int nb = 1 << bits[p];
         for (int i = threadIdx.x; i < nb; i += NT) s.hist[i] = 0u;
         __syncthreads();
-        for (int i = threadIdx.x; i < tv.npix; i += NT) {
-            const double v = chain_value(pg, upto, params, heq, tv.raw(i));
-            if (!in_set(cs, tv, i, v)) continue;
-            const unsigned long long key = dkey(v);
-            if ((key & pmask) != prefix) continue;
-            atomicAdd(&s.hist[(unsigned)((key >> shifts[p]) & (unsigned long long)(nb - 1))], 1u);
+        for (int i0 = 0; i0 < tv.npix; i0 += NT) {           // whole waves stay in the loop: hist_add uses ballots
+            const int i = i0 + threadIdx.x;
+            bool act = i < tv.npix;
+            unsigned bin = 0u;
+            if (act) {
+                const double v = chain_value(pg, upto, params, heq, tv.raw(i));
+                act = in_set(cs, tv, i, v);
+                if (act) {
+                    const unsigned long long key = dkey(v);
+                    act = (key & pmask) == prefix;
+                    bin = (unsigned)((key >> shifts[p]) & (unsigned long long)(nb - 1));
+                }
+            }
+            hist_add(s.hist, bin, act);
         }
         __syncthreads();
         // locate the bucket holding rank k: thread t owns bins 2t, 2t+1; exclusive scan of the pair sums
@@ -347,15 +375,20 @@ __device__ void histeq_run(Smem& s, const TileView& tv, const PreProgram& pg, in
     auto edge = [&](int i) { return i == 256 ? last : (double)i * step + first; };       // np.linspace
     for (int i = threadIdx.x; i < 256; i += NT) s.hist[i] = 0u;
     __syncthreads();
-    for (int i = threadIdx.x; i < tv.npix; i += NT) {
-        const double v = chain_value(pg, upto, params, heq, tv.raw(i));
-        int idx = (int)(((v - first) / (last - first)) * 256.0);
-        if (idx == 256) idx = 255;
-        if (idx < 0) idx = 0;
-        if (idx > 255) idx = 255;
-        if (v < edge(idx)) idx -= 1;
-        else if (v >= edge(idx + 1) && idx != 255) idx += 1;
-        atomicAdd(&s.hist[idx], 1u);
+    for (int i0 = 0; i0 < tv.npix; i0 += NT) {
+        const int i = i0 + threadIdx.x;
+        const bool act = i < tv.npix;
+        int idx = 0;
+        if (act) {
+            const double v = chain_value(pg, upto, params, heq, tv.raw(i));
+            idx = (int)(((v - first) / (last - first)) * 256.0);
+            if (idx == 256) idx = 255;
+            if (idx < 0) idx = 0;
+            if (idx > 255) idx = 255;
+            if (v < edge(idx)) idx -= 1;
+            else if (v >= edge(idx + 1) && idx != 255) idx += 1;
+        }
+        hist_add(s.hist, (unsigned)idx, act);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
