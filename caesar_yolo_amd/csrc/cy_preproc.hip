@@ -130,6 +130,26 @@ struct TileView {
     __device__ __forceinline__ double raw(int i) const { const int y = i / tw, x = i - y * tw; return (double)base[(size_t)y * MW + x]; }
 };
 
+// One pass over the tile, four pixels per thread in flight.  Every statistics pass re-reads the raw tile (1-1.6 MB per
+// workgroup, dozens of passes for a sigma-clip stage), and with one dependent load per thread and iteration the passes ran
+// at ~2 TB/s chip-wide, latency-bound; batching the loads keeps each thread's pixel ORDER (i = tid, tid+NT, ...), so sums
+// are bit-identical.  f(i, raw, ok) is called by every lane of the workgroup (ok = false past the end): it may ballot.
+template <typename F>
+__device__ __forceinline__ void for_pixels(const TileView& tv, F&& f) {
+    for (int i0 = 0; i0 < tv.npix; i0 += 4 * NT) {
+        double r[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * NT + (int)threadIdx.x;
+            ok[u] = i < tv.npix;
+            r[u] = ok[u] ? tv.raw(i) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) f(i0 + u * NT + (int)threadIdx.x, r[u], ok[u]);
+    }
+}
+
 // membership of pixel value v in the current sigma-clip set
 struct ClipSet { double L, U; int use_box, bx0, bx1, by0, by1; };
 __device__ __forceinline__ bool in_set(const ClipSet& cs, const TileView& tv, int i, double v) {
@@ -168,12 +188,10 @@ __device__ unsigned long long radix_select(Smem& s, const TileView& tv, const Pr
         const int nb = 1 << bits[p];
         for (int i = threadIdx.x; i < nb; i += NT) s.hist[i] = 0u;
         __syncthreads();
-        for (int i0 = 0; i0 < tv.npix; i0 += NT) {           // whole waves stay in the loop: hist_add uses ballots
-            const int i = i0 + threadIdx.x;
-            bool act = i < tv.npix;
+        for_pixels(tv, [&](int i, double rv, bool act) {      // whole waves stay in the pass: hist_add uses ballots
             unsigned bin = 0u;
             if (act) {
-                const double v = chain_value(pg, upto, params, heq, tv.raw(i));
+                const double v = chain_value(pg, upto, params, heq, rv);
                 act = in_set(cs, tv, i, v);
                 if (act) {
                     const unsigned long long key = dkey(v);
@@ -182,7 +200,7 @@ __device__ unsigned long long radix_select(Smem& s, const TileView& tv, const Pr
                 }
             }
             hist_add(s.hist, bin, act);
-        }
+        });
         __syncthreads();
         // locate the bucket holding rank k: thread t owns bins 2t, 2t+1; exclusive scan of the pair sums
         const int t = threadIdx.x;
@@ -220,11 +238,12 @@ __device__ double set_median(Smem& s, const TileView& tv, const PreProgram& pg, 
     if (n & 1ull) return a;
     // even count: the upper middle is `a` again if duplicates cover rank n/2, else the smallest value above `a`
     double cle = 0.0, nxt = INFINITY;
-    for (int i = threadIdx.x; i < tv.npix; i += NT) {
-        const double v = chain_value(pg, upto, params, heq, tv.raw(i));
-        if (!in_set(cs, tv, i, v)) continue;
+    for_pixels(tv, [&](int i, double rv, bool ok) {
+        if (!ok) return;
+        const double v = chain_value(pg, upto, params, heq, rv);
+        if (!in_set(cs, tv, i, v)) return;
         if (v <= a) cle += 1.0; else nxt = fmin(nxt, v);
-    }
+    });
     cle = block_sum(s, cle);
     nxt = block_min(s, nxt);
     const double b = (cle >= (double)(n / 2 + 1)) ? a : nxt;
@@ -244,20 +263,22 @@ __device__ ClipStats sigma_clip_run(Smem& s, const TileView& tv, const PreProgra
     }
     ClipStats r{NAN, NAN, NAN, NAN, NAN, 0ull};
     double cnt = 0.0, sum = 0.0;
-    for (int i = threadIdx.x; i < tv.npix; i += NT) {
-        const double v = chain_value(pg, upto, params, heq, tv.raw(i));
+    for_pixels(tv, [&](int i, double rv, bool ok) {
+        if (!ok) return;
+        const double v = chain_value(pg, upto, params, heq, rv);
         if (in_set(cs, tv, i, v)) { cnt += 1.0; sum += v; }
-    }
+    });
     cnt = block_sum(s, cnt); sum = block_sum(s, sum);
     unsigned long long n = (unsigned long long)cnt;
     bool fresh = false;                      // are mean/median/std valid for the CURRENT set?
     for (int it = 0; it < 5 && n > 0; ++it) {
         const double mean = sum / (double)n;
         double ssq = 0.0;
-        for (int i = threadIdx.x; i < tv.npix; i += NT) {
-            const double v = chain_value(pg, upto, params, heq, tv.raw(i));
+        for_pixels(tv, [&](int i, double rv, bool ok) {
+            if (!ok) return;
+            const double v = chain_value(pg, upto, params, heq, rv);
             if (in_set(cs, tv, i, v)) { const double d = v - mean; ssq += d * d; }
-        }
+        });
         ssq = block_sum(s, ssq);
         const double sd = sqrt(ssq / (double)n);
         const double med = set_median(s, tv, pg, upto, params, heq, cs, n);
@@ -265,10 +286,11 @@ __device__ ClipStats sigma_clip_run(Smem& s, const TileView& tv, const PreProgra
         r.lo = med - sd * slo; r.hi = med + sd * sup;
         cs.L = fmax(cs.L, r.lo); cs.U = fmin(cs.U, r.hi);
         double c2 = 0.0, s2 = 0.0;
-        for (int i = threadIdx.x; i < tv.npix; i += NT) {
-            const double v = chain_value(pg, upto, params, heq, tv.raw(i));
+        for_pixels(tv, [&](int i, double rv, bool ok) {
+            if (!ok) return;
+            const double v = chain_value(pg, upto, params, heq, rv);
             if (in_set(cs, tv, i, v)) { c2 += 1.0; s2 += v; }
-        }
+        });
         c2 = block_sum(s, c2); s2 = block_sum(s, s2);
         const unsigned long long n2 = (unsigned long long)c2;
         const bool changed = n2 != n;
@@ -279,10 +301,11 @@ __device__ ClipStats sigma_clip_run(Smem& s, const TileView& tv, const PreProgra
     if (!fresh && n > 0) {                   // stopped by maxiters: statistics of the final survivors
         const double mean = sum / (double)n;
         double ssq = 0.0;
-        for (int i = threadIdx.x; i < tv.npix; i += NT) {
-            const double v = chain_value(pg, upto, params, heq, tv.raw(i));
+        for_pixels(tv, [&](int i, double rv, bool ok) {
+            if (!ok) return;
+            const double v = chain_value(pg, upto, params, heq, rv);
             if (in_set(cs, tv, i, v)) { const double d = v - mean; ssq += d * d; }
-        }
+        });
         ssq = block_sum(s, ssq);
         r.mean = mean; r.std = sqrt(ssq / (double)n); r.median = set_median(s, tv, pg, upto, params, heq, cs, n); r.n = n;
     }
@@ -364,10 +387,11 @@ __device__ void zscale_run(Smem& s, const TileView& tv, const PreProgram& pg, in
 // skimage equalize_hist tables: np.histogram(image, 256) over [min,max] (zeros included), cdf, bin centres
 __device__ void histeq_run(Smem& s, const TileView& tv, const PreProgram& pg, int upto, const double* params, double* heq) {
     double mn = INFINITY, mx = -INFINITY;
-    for (int i = threadIdx.x; i < tv.npix; i += NT) {
-        const double v = chain_value(pg, upto, params, heq, tv.raw(i));
+    for_pixels(tv, [&](int i, double rv, bool ok) {
+        if (!ok) return;
+        const double v = chain_value(pg, upto, params, heq, rv);
         mn = fmin(mn, v); mx = fmax(mx, v);
-    }
+    });
     mn = block_min(s, mn); mx = block_max(s, mx);
     double first = mn, last = mx;
     if (first == last) { first -= 0.5; last += 0.5; }
@@ -375,12 +399,10 @@ __device__ void histeq_run(Smem& s, const TileView& tv, const PreProgram& pg, in
     auto edge = [&](int i) { return i == 256 ? last : (double)i * step + first; };       // np.linspace
     for (int i = threadIdx.x; i < 256; i += NT) s.hist[i] = 0u;
     __syncthreads();
-    for (int i0 = 0; i0 < tv.npix; i0 += NT) {
-        const int i = i0 + threadIdx.x;
-        const bool act = i < tv.npix;
+    for_pixels(tv, [&](int i, double rv, bool act) {
         int idx = 0;
         if (act) {
-            const double v = chain_value(pg, upto, params, heq, tv.raw(i));
+            const double v = chain_value(pg, upto, params, heq, rv);
             idx = (int)(((v - first) / (last - first)) * 256.0);
             if (idx == 256) idx = 255;
             if (idx < 0) idx = 0;
@@ -389,7 +411,7 @@ __device__ void histeq_run(Smem& s, const TileView& tv, const PreProgram& pg, in
             else if (v >= edge(idx + 1) && idx != 255) idx += 1;
         }
         hist_add(s.hist, (unsigned)idx, act);
-    }
+    });
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned long long c = 0ull;
