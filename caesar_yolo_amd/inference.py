@@ -302,8 +302,26 @@ class SFinder(object):
         data, self.header = res
         self.image_id = utils.image_id_of(path)
         self.ny, self.nx = data.shape
+        self._beam_info()
         det = self.model.engine(self._device())
         return det, det.mosaic_to_device(data, big_endian=True)
+
+    def _beam_info(self):
+        """Beam / pixel metadata of the reference's read_img (caesar_yolo/inference.py:430-468): beamArea = pi*BMAJ*BMIN /
+        (4 ln 2) / |CDELT1*CDELT2| pixels, 0 when any of the five keywords is missing (a warning per keyword, as there)."""
+        h = self.header
+        self.beamArea, ok = 0, True
+        for key, attr in (("CDELT1", "dX"), ("CDELT2", "dY"), ("BMAJ", "bmaj"), ("BMIN", "bmin"), ("BPA", "pa")):
+            if key not in h:
+                logger.warning("%s keyword missing in header!" % key)
+                ok = False
+            else:
+                setattr(self, attr, h[key])
+        if ok:
+            self.pixelArea = np.abs(self.dX * self.dY)
+            self.beamArea = np.pi * self.bmaj * self.bmin / (4 * np.log(2)) / self.pixelArea
+            logger.info("Image info: beam(%f,%f,%f), beamArea=%f, dx=%f, dy=%f, pixArea=%g" % (
+                self.bmaj * 3600, self.bmin * 3600, self.pa, self.beamArea, self.dX * 3600, self.dY * 3600, self.pixelArea))
 
     def _device(self):
         devs = self.config.get('devices', ['0'])

@@ -93,3 +93,22 @@ def test_ds9_region_writer(tmp_path):
     assert lines[3] == "box(4.5000,102.5000,7.0000,3.0000,0.00000000) # text={S2_t3} tag={extended} tag={BORDER} tag={MERGED} color=green"
     assert utils.ds9_region_lines(objs[1:], merged_tag=False)[0].count("tag=") == 2      # Analyzer regions carry no MERGED tag
     assert utils.write_ds9_regions(str(tmp_path / "e.reg"), []) == 0 and not (tmp_path / "e.reg").exists()
+
+
+def test_beam_metadata_from_header(golden_dir, tmp_path):
+    """SFinder's beam/pixel metadata (caesar_yolo/inference.py:430-468): the formula on a header with all five keywords, and
+    the all-keywords-or-nothing rule on the reference's own FITS fixture (it has BMAJ/BMIN/BPA but no CDELT1/2 -> 0)."""
+    from caesar_yolo_amd.inference import SFinder
+    sf = SFinder.__new__(SFinder)
+    _, sf.header = utils.read_fits_image(os.path.join(golden_dir, "galaxy0001.fits"))
+    sf._beam_info()
+    assert sf.beamArea == 0 and sf.pa == sf.header["BPA"]
+    img = np.zeros((8, 8), np.float32)
+    cards = [("CDELT1", -2.777777777778e-4), ("CDELT2", 2.777777777778e-4), ("BMAJ", 0.002611826449586),
+             ("BMIN", 0.002142504259875), ("BPA", 84.46066805677)]
+    utils.write_fits_image(str(tmp_path / "beam.fits"), img, cards)
+    _, sf.header = utils.read_fits_image(str(tmp_path / "beam.fits"))
+    sf._beam_info()
+    h = dict(cards)
+    expect = np.pi * h["BMAJ"] * h["BMIN"] / (4 * np.log(2)) / abs(h["CDELT1"] * h["CDELT2"])
+    assert abs(sf.beamArea - expect) <= 1e-12 * expect and 80.0 < sf.beamArea < 90.0
