@@ -44,6 +44,7 @@ struct cy_ctx {
     unsigned long batches = 0;                          // cy_detect_tiles calls since load / flush
     // optional per-launch timing of the forward ops (hipEvents on the caller's stream)
     bool profiling = false;
+    int prof_stride = 1; unsigned long fwd_calls = 0;   // profiling on: every prof_stride-th cy_forward call is timed
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
     struct ProfRec { size_t e0, e1; int kind; double flops; int conv; };
     std::vector<ProfRec> prof;
@@ -188,8 +189,13 @@ int upload_weights(cy_ctx* c, const void* buf, size_t nbytes) {
         HIPCHK(c, hipMalloc(&b.pre_histeq, Bm * 3 * 520 * sizeof(double)));
         HIPCHK(c, hipMalloc(&b.pre_scratch, c->pre_scratch_elems * sizeof(double)));
     }
-    HIPCHK(c, hipStreamCreateWithFlags(&c->s_pre, hipStreamNonBlocking));
-    HIPCHK(c, hipStreamCreateWithFlags(&c->s_post, hipStreamNonBlocking));
+    // side streams at the LOWEST priority: preprocessing and decode/NMS/merge fill the gaps of the conv stack on the caller's
+    // stream instead of competing with it for CUs (CY_SIDE_PRIO=0 restores default-priority streams)
+    int prio_lo = 0, prio_hi = 0;
+    hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);          // lo = numerically greatest = lowest priority
+    const bool low = !(getenv("CY_SIDE_PRIO") && atoi(getenv("CY_SIDE_PRIO")) == 0);
+    HIPCHK(c, hipStreamCreateWithPriority(&c->s_pre, hipStreamNonBlocking, low ? prio_lo : 0));
+    HIPCHK(c, hipStreamCreateWithPriority(&c->s_post, hipStreamNonBlocking, low ? prio_lo : 0));
     hipEvent_t* evs[] = {&c->ev_call, &c->ev_pre[0], &c->ev_pre[1], &c->ev_fwd[0], &c->ev_fwd[1], &c->ev_post[0], &c->ev_post[1]};
     for (hipEvent_t* e : evs) HIPCHK(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
     c->loaded = true;
@@ -319,10 +325,11 @@ int cy_forward(cy_ctx* c, const void* d_netin, int B, int H, int W, float* d_pre
         hipEventRecord(c->ev_pool[c->ev_used], s);
         return c->ev_used++;
     };
-    size_t ev_prev = c->profiling ? stamp() : 0;
+    const bool prof_now = c->profiling && (c->fwd_calls++ % (unsigned long)c->prof_stride) == 0;
+    size_t ev_prev = prof_now ? stamp() : 0;
     int cur_conv = -1;
     auto prof_done = [&](int kind, double flops) {
-        if (!c->profiling) return;
+        if (!prof_now) return;
         const size_t e = stamp();
         c->prof.push_back({ev_prev, e, kind, flops, cur_conv});
         ev_prev = e;
@@ -415,6 +422,8 @@ int cy_forward(cy_ctx* c, const void* d_netin, int B, int H, int W, float* d_pre
 int cy_profile_enable(cy_ctx* c, int on) {
     if (!c) return CY_ERR_ARG;
     c->profiling = on != 0;
+    c->prof_stride = on > 1 ? on : 1;                    // on = N > 1: time every N-th forward call only (an event per launch costs ~3 % at N = 1)
+    c->fwd_calls = 0;
     c->prof.clear(); c->ev_used = 0;
     return CY_OK;
 }

@@ -122,7 +122,7 @@ class HipDetector(object):
         return pred
 
     def profile(self, on):
-        self._chk(self.lib.cy_profile_enable(self.ctx, int(bool(on))))
+        self._chk(self.lib.cy_profile_enable(self.ctx, int(on)))            # True/1: every forward call; N > 1: every N-th
 
     def profile_summary(self):
         ent = (L.cy_prof_entry * 32)()

@@ -99,7 +99,7 @@ int cy_forward(cy_ctx* ctx, const void* d_netin, int B, int H, int W, float* d_p
  * cy_forward / cy_detect_tiles as usual, then read the totals per kernel variant (up to 8 entries: the conv variants,
  * stem, pool); flops are the ALGORITHMIC 2*MACs of the launches timed */
 typedef struct cy_prof_entry { char kernel[64]; double ms; double flops; long launches; } cy_prof_entry;
-int cy_profile_enable(cy_ctx* ctx, int on);
+int cy_profile_enable(cy_ctx* ctx, int on);    /* 0 off, 1 every cy_forward call, N > 1 every N-th call (sampling) */
 int cy_profile_summary(cy_ctx* ctx, cy_prof_entry* out, int cap);
 int cy_profile_layers(cy_ctx* ctx, cy_prof_entry* out, int cap);    /* the same, one entry per convolution (graph order) */
 /* copy the output of one named convolution of the last cy_forward to host as fp32 [B][C][Ho][Wo] (test hook) */
