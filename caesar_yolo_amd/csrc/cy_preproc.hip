@@ -136,6 +136,9 @@ struct TileView {
 // are bit-identical.  f(i, raw, ok) is called by every lane of the workgroup (ok = false past the end): it may ballot.
 template <typename F>
 __device__ __forceinline__ void for_pixels(const TileView& tv, F&& f) {
+    // (y, x) of the thread's next pixel, advanced by NT pixels per load: one integer division per pass, not per pixel
+    int y = (int)threadIdx.x / tv.tw, x = (int)threadIdx.x - y * tv.tw;
+    const int dy = NT / tv.tw, dx = NT - dy * tv.tw;
     for (int i0 = 0; i0 < tv.npix; i0 += 4 * NT) {
         double r[4];
         bool ok[4];
@@ -143,7 +146,9 @@ __device__ __forceinline__ void for_pixels(const TileView& tv, F&& f) {
         for (int u = 0; u < 4; ++u) {
             const int i = i0 + u * NT + (int)threadIdx.x;
             ok[u] = i < tv.npix;
-            r[u] = ok[u] ? tv.raw(i) : 0.0;
+            r[u] = ok[u] ? (double)tv.base[(size_t)y * tv.MW + x] : 0.0;
+            x += dx; y += dy;
+            if (x >= tv.tw) { x -= tv.tw; ++y; }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) f(i0 + u * NT + (int)threadIdx.x, r[u], ok[u]);
