@@ -70,3 +70,44 @@ def test_conv_bn_silu(prec, case):
     tol = (2e-5 if prec == "fp32" else 4e-3) * max(scale, 1.0)
     err = float((got - y).abs().max())
     assert err <= tol, "max abs err %.3e > %.3e (scale %.2f)" % (err, tol, scale)
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_conv_random_geometry_fp16(seed, monkeypatch):
+    """Seeded random layer geometries around the dispatch boundaries of launch_conv (channel counts that are / are not
+    multiples of 64 and 128, map widths around 16/32, ragged pixel tails, stride 1/2, k 1/3, residual on/off), with the
+    pixels-direct kernel forced on for half of the seeds so that it also sees shapes it would not pick by itself."""
+    rng = np.random.default_rng(1000 + seed)
+    k = int(rng.choice([1, 3]))
+    s = int(rng.choice([1, 2])) if k == 3 else 1
+    Cin = int(rng.choice([64, 128, 192, 256, 320]))
+    Cout = int(rng.choice([40, 64, 96, 128, 160, 192, 256, 320]))
+    H = int(rng.choice([15, 16, 31, 32, 33, 48, 64]))
+    Wd = int(rng.choice([16, 30, 32, 34, 62, 64, 96]))
+    B = int(rng.choice([1, 3, 8, 24]))
+    act = bool(rng.integers(0, 2))
+    use_res = bool(rng.integers(0, 2))
+    if seed % 2:
+        monkeypatch.setenv("CY_DIRECT_MIN_BLOCKS", "1")
+    det = detector("fp16")
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.randn((B, Cin, H, Wd), generator=g)).half().float()
+    w = (torch.randn((Cout, Cin, k, k), generator=g) / (Cin * k * k) ** 0.5).half().float()
+    b = torch.randn((Cout,), generator=g) * 0.1
+    y = F.conv2d(x, w, b, stride=s, padding=k // 2)
+    if act:
+        y = F.silu(y)
+    res = None
+    if use_res:
+        res = torch.randn(y.shape, generator=g).half().float()
+        y = y + res
+    xd = x.permute(0, 2, 3, 1).contiguous().half().cuda()
+    rd = res.permute(0, 2, 3, 1).contiguous().half().cuda() if use_res else None
+    out = det.conv_bn_silu(xd, w.numpy(), b.numpy(), k, s, act, rd)
+    torch.cuda.synchronize()
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    assert got.shape == y.shape
+    scale = max(float(y.abs().max()), 1.0)
+    err = float((got - y).abs().max())
+    assert err <= 4e-3 * scale, "B%d %dx%d %d->%d k%d s%d act%d res%d: max abs err %.3e (scale %.2f)" % (
+        B, H, Wd, Cin, Cout, k, s, act, use_res, err, scale)
