@@ -1,0 +1,131 @@
+// YOLO11-only operators: depth-wise 3x3 convolution and the C2PSA attention core.
+// Both are a fraction of a percent of the network's work (the detect head's depth-wise branch moves ~100 MB per 64-tile
+// batch, attention runs on the 16x16 stride-32 map only), so they are written for clarity: HBM-bound element kernels in
+// the activation type with fp32 arithmetic, not MFMA tiles.  Definitions follow the public ultralytics modules
+// (Conv with g = c, Attention in nn/modules/block.py); parity is against oracle/yolo11_ref.py (unpinned to ultralytics).
+#include "cy_kernels.h"
+
+namespace cy {
+
+typedef _Float16 f16;
+
+template <typename T> struct Vec8;
+template <> struct Vec8<f16> { typedef f16 type __attribute__((ext_vector_type(8))); };
+template <> struct Vec8<float> { typedef float type __attribute__((ext_vector_type(8))); };
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+
+// ------------------------------------------------------------------------------------------------ depth-wise 3x3, stride 1
+// out[b,y,x,c] = act( sum_{kh,kw} in[b,y+kh-1,x+kw-1,map(c)] * w[kh*3+kw][c] + bias[c] ) (+ res[b,y,x,c])
+// One thread = one pixel x 8 channels (16-byte loads in fp16).  map(c) is the identity, or - for the positional-encoding
+// conv of the attention block - the channel of `v` inside the per-head [q|k|v] blocks of the qkv tensor:
+// map(c) = (c / blk) * gstride + goff + c % blk  (blk is a multiple of 8).
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(const DwArgs a) {
+    typedef typename Vec8<T>::type v8;
+    const int cg = a.C / 8;
+    const long total = (long)a.B * a.H * a.W * cg;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int g8 = (int)(idx % cg);
+        const long pix = idx / cg;
+        const int x = (int)(pix % a.W), y = (int)((pix / a.W) % a.H), b = (int)(pix / ((long)a.W * a.H));
+        const int c = g8 * 8;
+        const int cin = a.blk ? (c / a.blk) * a.gstride + a.goff + c % a.blk : c;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = a.bias[c + j];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int yy = y + kh - 1, xx = x + kw - 1;
+                if ((unsigned)yy >= (unsigned)a.H || (unsigned)xx >= (unsigned)a.W) continue;
+                const T* ip = reinterpret_cast<const T*>(a.in) + (((long)b * a.H + yy) * a.W + xx) * a.in_ct + a.in_coff + cin;
+                const v8 v = *reinterpret_cast<const v8*>(ip);
+                const float* w = a.w + (kh * 3 + kw) * a.C + c;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf((float)v[j], w[j], acc[j]);
+            }
+        v8 o;
+        const long opix = ((long)b * a.H + y) * a.W + x;
+        if (a.res) {
+            const v8 r = *reinterpret_cast<const v8*>(reinterpret_cast<const T*>(a.res) + opix * a.res_ct + a.res_coff + c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (T)((a.act ? silu_f(acc[j]) : acc[j]) + (float)r[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (T)(a.act ? silu_f(acc[j]) : acc[j]);
+        }
+        *reinterpret_cast<v8*>(reinterpret_cast<T*>(a.out) + opix * a.out_ct + a.out_coff + c) = o;
+    }
+}
+
+hipError_t launch_dwconv(Precision p, const DwArgs& a, hipStream_t s) {
+    if (a.C % 8 || (a.blk && a.blk % 8)) return hipErrorInvalidValue;
+    const long total = (long)a.B * a.H * a.W * (a.C / 8);
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (p == PREC_F16) hipLaunchKernelGGL(dwconv3x3_kernel<f16>, dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(dwconv3x3_kernel<float>, dim3(grid), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ attention core (C2PSA)
+// qkv: [B][N][heads*(2*kd+hd)] (N = H*W pixels of the stride-32 map), per head the channels [q: kd | k: kd | v: hd].
+// out[b][n][head*hd + c] = sum_m softmax_m( scale * <q_n, k_m> ) * v[m][c],  scale = kd^-0.5.
+// One wave per query: lanes stride over the keys for the scores (kept in LDS), wave-reduce max and sum, then lane c
+// accumulates channel c over all keys (hd = 64 = one channel per lane).  fp32 arithmetic throughout.
+template <typename T>
+__global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
+    extern __shared__ float sc[];                            // [4 waves][N]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int per = a.kd * 2 + a.hd;
+    const long q_id = (long)blockIdx.x * 4 + wave;           // (b, head, n)
+    const long nq = (long)a.B * a.heads * a.N;
+    if (q_id >= nq) return;
+    const int n = (int)(q_id % a.N), head = (int)((q_id / a.N) % a.heads), b = (int)(q_id / ((long)a.N * a.heads));
+    const T* base = reinterpret_cast<const T*>(a.qkv) + (long)b * a.N * a.ct + a.coff + head * per;
+    float* s = sc + wave * a.N;
+    float q[64];                                             // kd <= 64
+    const T* qp = base + (long)n * a.ct;
+    for (int d = 0; d < a.kd; ++d) q[d] = (float)qp[d];
+    float mx = -INFINITY;
+    for (int m = lane; m < a.N; m += 64) {
+        const T* kp = base + (long)m * a.ct + a.kd;
+        float t = 0.0f;
+        for (int d = 0; d < a.kd; ++d) t = fmaf(q[d], (float)kp[d], t);
+        t *= a.scale;
+        s[m] = t;
+        mx = fmaxf(mx, t);
+    }
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    float sum = 0.0f;
+    for (int m = lane; m < a.N; m += 64) { const float e = expf(s[m] - mx); s[m] = e; sum += e; }
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0xc07f);                      // this wave's score row is complete in LDS
+    const float inv = 1.0f / sum;
+    for (int c = lane; c < a.hd; c += 64) {
+        float acc = 0.0f;
+        const T* vp = base + 2 * a.kd + c;
+        for (int m = 0; m < a.N; ++m) acc = fmaf(s[m], (float)vp[(long)m * a.ct], acc);
+        reinterpret_cast<T*>(a.out)[((long)b * a.N + n) * a.out_ct + a.out_coff + head * a.hd + c] = (T)(acc * inv);
+    }
+}
+
+hipError_t launch_attention(Precision p, const AttnArgs& a, hipStream_t s) {
+    if (a.kd > 64 || a.kd < 1 || a.hd < 1 || a.N < 1 || (size_t)a.N * 16 > 160 * 1024) return hipErrorInvalidValue;
+    const long nq = (long)a.B * a.heads * a.N;
+    const size_t lds = (size_t)4 * a.N * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const int grid = (int)((nq + 3) / 4);
+    if (p == PREC_F16) hipLaunchKernelGGL(attention_kernel<f16>, dim3(grid), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(attention_kernel<float>, dim3(grid), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace cy

@@ -38,6 +38,18 @@ struct PoolArgs {   // MaxPool2d(5,1,2) on a channel slice of an NHWC buffer, -i
     const void* src; void* dst; int ct, src_coff, dst_coff, C, B, H, W;
 };
 
+// YOLO11 operators (cy_extra.hip)
+struct DwArgs {     // depth-wise 3x3 stride 1 over NHWC channel slices; w: [9][C] fp32, bias [C] fp32
+    const void* in; int in_ct, in_coff; void* out; int out_ct, out_coff; const void* res; int res_ct, res_coff;
+    const float* w; const float* bias; int B, H, W, C, act;
+    int blk, gstride, goff;                            // input channel of output channel c: (c/blk)*gstride + goff + c%blk (blk = 0: c)
+};
+struct AttnArgs {   // softmax(q^T k * scale) applied to v, per head; qkv channels per head: [q kd | k kd | v hd]
+    const void* qkv; int ct, coff; void* out; int out_ct, out_coff; int B, N, heads, kd, hd; float scale;
+};
+hipError_t launch_dwconv(Precision p, const DwArgs& a, hipStream_t s);
+hipError_t launch_attention(Precision p, const AttnArgs& a, hipStream_t s);
+
 hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s);
 enum ConvVariant { CONV_GENERIC_128 = 0, CONV_GENERIC_64, CONV_HALO8_128, CONV_PP_64, CONV_PP_128, CONV_HALO16_128, CONV_C64_PERSIST, CONV_GENERIC_BIG, CONV_WIDE_128, CONV_DIRECT_256, CONV_DIRECT_128, CONV_WIDE_64, CONV_NUM_VARIANTS };
 int conv_variant(Precision p, const ConvArgs& a);          // which kernel launch_conv picks

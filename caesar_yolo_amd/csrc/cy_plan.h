@@ -7,11 +7,11 @@
 
 namespace cy {
 
-struct ConvDesc { std::string name; int cin, cout, k, s, act; };
+struct ConvDesc { std::string name; int cin, cout, k, s, act; int groups = 1; };
 
 struct Tensor { int level; int C; };          // spatial size = (H >> level, W >> level), C channels per pixel
 
-enum OpKind { OPK_STEM = 0, OPK_CONV = 1, OPK_POOL = 2 };
+enum OpKind { OPK_STEM = 0, OPK_CONV = 1, OPK_POOL = 2, OPK_DWCONV = 3, OPK_ATTN = 4 };   // 3, 4: YOLO11 plans (CYW2 files)
 
 struct Op {
     OpKind kind;
@@ -21,10 +21,12 @@ struct Op {
     int out, out_coff;                         // destination tensor slice, or out = -1 for the head output
     int res, res_coff;                         // residual tensor slice or res = -1
     int pred_level, pred_coff;                 // when out == -1: which stride level, channel offset inside [64+nc]
+    int p0 = 0, p1 = 0, p2 = 0, p3 = 0;        // DWCONV: input channel map (blk, gstride, goff); ATTN: heads, key_dim, head_dim
 };
 
 struct Plan {
     char scale; int nc;
+    std::string arch = "yolov8";
     std::vector<ConvDesc> convs;               // canonical (state_dict) order == weight-file order
     std::vector<Tensor> tensors;               // tensor 0 is the network input [B,H,W,4]
     std::vector<Op> ops;                       // execution order

@@ -12,7 +12,8 @@
 
 using namespace cy;
 
-struct DevConv { void* w = nullptr; float* bias = nullptr; size_t wbytes = 0; float* stem_w = nullptr; void* w32 = nullptr; size_t w32bytes = 0; };
+struct DevConv { void* w = nullptr; float* bias = nullptr; size_t wbytes = 0; float* stem_w = nullptr; void* w32 = nullptr; size_t w32bytes = 0;
+                 float* dw_w = nullptr; };     // dw_w: depth-wise 3x3 weights [9][C] fp32 (YOLO11)
 
 struct cy_ctx {
     int device = 0;
@@ -73,7 +74,7 @@ size_t tensor_elems_per_tile(const Plan& p, int H, int W) {
 void free_all(cy_ctx* c) {
     for (auto e : c->ev_pool) hipEventDestroy(e);
     c->ev_pool.clear(); c->ev_used = 0; c->prof.clear();
-    for (auto& d : c->dconv) { if (d.w) hipFree(d.w); if (d.bias) hipFree(d.bias); if (d.stem_w) hipFree(d.stem_w); if (d.w32) hipFree(d.w32); }
+    for (auto& d : c->dconv) { if (d.w) hipFree(d.w); if (d.bias) hipFree(d.bias); if (d.stem_w) hipFree(d.stem_w); if (d.w32) hipFree(d.w32); if (d.dw_w) hipFree(d.dw_w); }
     c->dconv.clear();
     if (c->ws) hipFree(c->ws);
     c->ws = nullptr;
@@ -97,30 +98,86 @@ struct Reader {
     const float* f32(size_t cnt) { if (o + 4 * cnt > n) { bad = true; return nullptr; } const float* r = (const float*)(p + o); o += 4 * cnt; return r; }
 };
 
+// CYW2: the execution plan travels in the file (caesar_yolo_amd/weights.py:write_cyw2, yolo11_graph.py)
+int parse_plan_v2(cy_ctx* c, Reader& r, Plan* plan, uint32_t* nconv_out, std::vector<std::string>* names) {
+    if (r.u32() != 2) return fail(c, CY_ERR_IO, "unsupported CYW2 version");
+    if (r.o + 12 > r.n) return fail(c, CY_ERR_IO, "truncated weight file");
+    plan->arch = std::string((const char*)r.p + r.o, strnlen((const char*)r.p + r.o, 8)); r.o += 8;
+    plan->scale = (char)r.p[r.o]; r.o += 4;
+    const uint32_t nc = r.u32(), nnames = r.u32(), nt = r.u32(), nops = r.u32(), nconv = r.u32();
+    for (int l = 0; l < 3; ++l) plan->feat_level[l] = (int)r.u32();
+    if (r.bad || nc < 1 || nc > 1000 || nt < 2 || nt > 4096 || nops < 1 || nops > 8192 || nconv < 1 || nconv > 4096)
+        return fail(c, CY_ERR_IO, "implausible CYW2 header");
+    plan->nc = (int)nc;
+    for (uint32_t i = 0; i < nnames; ++i) { uint32_t l = r.u32(); names->push_back(r.str(l)); }
+    for (uint32_t i = 0; i < nt; ++i) { const int lev = (int)r.u32(), C = (int)r.u32(); plan->tensors.push_back({lev, C}); }
+    for (uint32_t i = 0; i < nops; ++i) {
+        int v[20];
+        for (int j = 0; j < 20; ++j) v[j] = (int)r.u32();
+        Op o{};
+        o.kind = (OpKind)v[0]; o.conv = v[1]; o.in0 = v[2]; o.in0_coff = v[3]; o.c0 = v[4]; o.up0 = v[5];
+        o.in1 = v[6]; o.in1_coff = v[7]; o.c1 = v[8]; o.out = v[9]; o.out_coff = v[10]; o.res = v[11]; o.res_coff = v[12];
+        o.pred_level = v[13]; o.pred_coff = v[14]; o.p0 = v[15]; o.p1 = v[16]; o.p2 = v[17]; o.p3 = v[18];
+        auto tok = [&](int t, bool opt) { return (opt && t < 0) || (t >= 0 && t < (int)nt); };
+        if (r.bad || v[0] < 0 || v[0] > OPK_ATTN || !tok(o.in0, false) || !tok(o.in1, true) || !tok(o.out, true) || !tok(o.res, true) ||
+            (o.kind != OPK_POOL && o.kind != OPK_ATTN && (o.conv < 0 || o.conv >= (int)nconv)) ||
+            (o.out < 0 && (o.pred_level < 0 || o.pred_level > 2)))
+            return fail(c, CY_ERR_IO, "malformed op in CYW2 plan");
+        plan->ops.push_back(o);
+    }
+    if (r.bad) return fail(c, CY_ERR_IO, "truncated weight file");
+    for (auto& t : plan->tensors) if (t.level < 0 || t.level > 5 || t.C < 1 || t.C > 65536) return fail(c, CY_ERR_IO, "malformed tensor in CYW2 plan");
+    *nconv_out = nconv;
+    plan->ok = true;
+    return CY_OK;
+}
+
 int upload_weights(cy_ctx* c, const void* buf, size_t nbytes) {
     Reader r{(const unsigned char*)buf, nbytes};
-    if (nbytes < 24 || memcmp(buf, "CYW1", 4) != 0) return fail(c, CY_ERR_IO, "not a CYW1 weight file");
+    if (nbytes < 24 || (memcmp(buf, "CYW1", 4) != 0 && memcmp(buf, "CYW2", 4) != 0)) return fail(c, CY_ERR_IO, "not a CYW weight file");
+    const bool v2 = memcmp(buf, "CYW2", 4) == 0;
     r.o = 4;
-    if (r.u32() != 1) return fail(c, CY_ERR_IO, "unsupported CYW version");
-    const char scale = (char)r.p[r.o]; r.o += 4;
-    const uint32_t nc = r.u32(), nconv = r.u32(), nnames = r.u32();
-    Plan plan = build_plan(scale, (int)nc);
-    if (!plan.ok) return fail(c, CY_ERR_UNSUPPORTED, plan.err);
-    if (plan.convs.size() != nconv) return fail(c, CY_ERR_IO, "weight file conv count does not match the graph");
+    Plan plan;
+    uint32_t nc = 0, nconv = 0;
     std::vector<std::string> names;
-    for (uint32_t i = 0; i < nnames; ++i) { uint32_t l = r.u32(); names.push_back(r.str(l)); }
+    if (v2) {
+        plan.ok = false;
+        int rc = parse_plan_v2(c, r, &plan, &nconv, &names);
+        if (rc) return rc;
+        nc = (uint32_t)plan.nc;
+    } else {
+        if (r.u32() != 1) return fail(c, CY_ERR_IO, "unsupported CYW version");
+        const char scale = (char)r.p[r.o]; r.o += 4;
+        nc = r.u32(); nconv = r.u32();
+        const uint32_t nnames = r.u32();
+        plan = build_plan(scale, (int)nc);
+        if (!plan.ok) return fail(c, CY_ERR_UNSUPPORTED, plan.err);
+        if (plan.convs.size() != nconv) return fail(c, CY_ERR_IO, "weight file conv count does not match the graph");
+        for (uint32_t i = 0; i < nnames; ++i) { uint32_t l = r.u32(); names.push_back(r.str(l)); }
+    }
     HIPCHK(c, hipSetDevice(c->device));
     free_all(c);
     c->dconv.resize(nconv);
     std::vector<char> packed;
+    int stem_conv = -1;
+    for (auto& o : plan.ops) if (o.kind == OPK_STEM) stem_conv = o.conv;
     for (uint32_t i = 0; i < nconv; ++i) {
-        const uint32_t co = r.u32(), ci = r.u32(), k = r.u32(), s = r.u32(), act = r.u32(), nl = r.u32();
+        const uint32_t co = r.u32(), ci = r.u32(), k = r.u32(), s = r.u32(), act = r.u32();
+        const uint32_t groups = v2 ? r.u32() : 1u;
+        const uint32_t nl = r.u32();
         const std::string name = r.str(nl);
-        const ConvDesc& d = plan.convs[i];
         if (r.bad) return fail(c, CY_ERR_IO, "truncated weight file");
-        if (name != d.name || (int)co != d.cout || (int)ci != d.cin || (int)k != d.k || (int)s != d.s || (int)act != d.act)
-            return fail(c, CY_ERR_IO, "weight file layer " + name + " does not match graph layer " + d.name);
-        const float* W = r.f32((size_t)co * ci * k * k);
+        if (v2) {
+            if (co < 1 || ci < 1 || groups < 1 || ci % groups || (k != 1 && k != 3) || (s != 1 && s != 2))
+                return fail(c, CY_ERR_IO, "malformed conv header: " + name);
+            ConvDesc d; d.name = name; d.cin = (int)ci; d.cout = (int)co; d.k = (int)k; d.s = (int)s; d.act = (int)act; d.groups = (int)groups;
+            plan.convs.push_back(d);
+        } else {
+            const ConvDesc& d = plan.convs[i];
+            if (name != d.name || (int)co != d.cout || (int)ci != d.cin || (int)k != d.k || (int)s != d.s || (int)act != d.act)
+                return fail(c, CY_ERR_IO, "weight file layer " + name + " does not match graph layer " + d.name);
+        }
+        const float* W = r.f32((size_t)co * (ci / groups) * k * k);
         const float* b = r.f32(co);
         if (r.bad) return fail(c, CY_ERR_IO, "truncated weight file");
         DevConv& dc = c->dconv[i];
@@ -129,7 +186,15 @@ int upload_weights(cy_ctx* c, const void* buf, size_t nbytes) {
         memcpy(bias.data(), b, 4 * co);
         HIPCHK(c, hipMalloc(&dc.bias, 4 * cp));
         HIPCHK(c, hipMemcpy(dc.bias, bias.data(), 4 * cp, hipMemcpyHostToDevice));
-        if (i == 0) {   // stem: [27][Cout] fp32, t = (kh*3+kw)*3 + c over the 3 network input channels
+        if (groups > 1) {   // depth-wise 3x3 (YOLO11): [9][C] fp32 for dwconv3x3_kernel
+            if (groups != ci || co != ci || k != 3 || s != 1 || co % 8) return fail(c, CY_ERR_UNSUPPORTED, "only depth-wise 3x3 stride-1 grouped convs are supported: " + name);
+            std::vector<float> dw(9 * (size_t)co);
+            for (uint32_t ch = 0; ch < co; ++ch) for (int t = 0; t < 9; ++t) dw[(size_t)t * co + ch] = W[(size_t)ch * 9 + t];
+            HIPCHK(c, hipMalloc(&dc.dw_w, 4 * dw.size()));
+            HIPCHK(c, hipMemcpy(dc.dw_w, dw.data(), 4 * dw.size(), hipMemcpyHostToDevice));
+            continue;
+        }
+        if ((int)i == stem_conv) {   // stem: [27][Cout] fp32, t = (kh*3+kw)*3 + c over the 3 network input channels
             if (co > 64 || co % 16) return fail(c, CY_ERR_UNSUPPORTED, "stem width not supported by the gfx950 stem kernel");
             std::vector<float> sw(27 * co);
             for (uint32_t o = 0; o < co; ++o) for (int cch = 0; cch < 3; ++cch) for (int t = 0; t < 9; ++t)
@@ -378,6 +443,29 @@ int cy_forward(cy_ctx* c, const void* d_netin, int B, int H, int W, float* d_pre
             a.C = o.c0; a.B = Bn; a.H = H >> t.level; a.W = W >> t.level;
             HIPCHK(c, launch_pool5(c->prec, a, s));
             prof_done(CONV_NUM_VARIANTS + 1, 0.0);
+        } else if (o.kind == OPK_DWCONV) {
+            const ConvDesc& d = p.convs[o.conv];
+            const Tensor& ti = p.tensors[o.in0]; const Tensor& to = p.tensors[o.out];
+            DwArgs a{};
+            a.in = tp(o.in0); a.in_ct = ti.C; a.in_coff = o.in0_coff; a.out = tp(o.out); a.out_ct = to.C; a.out_coff = o.out_coff;
+            if (o.res >= 0) { a.res = tp(o.res); a.res_ct = p.tensors[o.res].C; a.res_coff = o.res_coff; }
+            a.w = c->dconv[o.conv].dw_w; a.bias = c->dconv[o.conv].bias;
+            a.B = Bn; a.H = H >> ti.level; a.W = W >> ti.level; a.C = d.cout; a.act = d.act;
+            a.blk = o.p0; a.gstride = o.p1; a.goff = o.p2;
+            if (!a.w || ti.level != to.level) return fail(c, CY_ERR_STATE, "malformed depth-wise op");
+            HIPCHK(c, launch_dwconv(c->prec, a, s));
+            prof_done(CONV_NUM_VARIANTS + 2, 2.0 * Bn * a.H * a.W * (double)a.C * 9.0);
+        } else if (o.kind == OPK_ATTN) {
+            const Tensor& ti = p.tensors[o.in0]; const Tensor& to = p.tensors[o.out];
+            AttnArgs a{};
+            a.qkv = tp(o.in0); a.ct = ti.C; a.coff = o.in0_coff; a.out = tp(o.out); a.out_ct = to.C; a.out_coff = o.out_coff;
+            a.B = Bn; a.N = (H >> ti.level) * (W >> ti.level); a.heads = o.p0; a.kd = o.p1; a.hd = o.p2;
+            a.scale = 1.0f / sqrtf((float)a.kd);
+            if (a.heads < 1 || ti.level != to.level) return fail(c, CY_ERR_STATE, "malformed attention op");
+            hipError_t e = launch_attention(c->prec, a, s);
+            if (e == hipErrorInvalidValue) return fail(c, CY_ERR_UNSUPPORTED, "attention map too large for this kernel (stride-32 map of the input must have <= 10240 pixels)");
+            HIPCHK(c, e);
+            prof_done(CONV_NUM_VARIANTS + 3, 2.0 * Bn * a.heads * (double)a.N * a.N * (a.kd + a.hd));
         } else {
             const ConvDesc& d = p.convs[o.conv];
             ConvArgs a{};
@@ -430,12 +518,13 @@ int cy_profile_enable(cy_ctx* c, int on) {
 
 int cy_profile_summary(cy_ctx* c, cy_prof_entry* out, int cap) {
     // one entry per forward kernel variant (conv variants in ConvVariant order, then stem, pool)
-    const int n = CONV_NUM_VARIANTS + 2;
+    const int n = CONV_NUM_VARIANTS + 4;
     if (!c || !out || cap < n) return fail(c, CY_ERR_ARG, "bad arguments");
     HIPCHK(c, hipDeviceSynchronize());
     for (int k = 0; k < n; ++k) {
         memset(&out[k], 0, sizeof(out[k]));
-        const char* nm = k < CONV_NUM_VARIANTS ? conv_variant_name(k) : (k == CONV_NUM_VARIANTS ? "stem_kernel" : "pool5_kernel");
+        static const char* const extra[4] = {"stem_kernel", "pool5_kernel", "dwconv3x3_kernel", "attention_kernel"};
+        const char* nm = k < CONV_NUM_VARIANTS ? conv_variant_name(k) : extra[k - CONV_NUM_VARIANTS];
         strncpy(out[k].kernel, nm, sizeof(out[k].kernel) - 1);
     }
     for (const auto& r : c->prof) {
@@ -466,7 +555,7 @@ int cy_debug_read_conv(cy_ctx* c, const char* conv_name, float* h_out, size_t ca
     if (c->lastB == 0) return fail(c, CY_ERR_STATE, "no forward has run");
     const Plan& p = c->plan;
     for (const Op& o : p.ops) {
-        if (o.kind == OPK_POOL || p.convs[o.conv].name != conv_name) continue;
+        if (o.conv < 0 || p.convs[o.conv].name != conv_name) continue;      // pool and attention ops carry no convolution
         if (o.out < 0) return fail(c, CY_ERR_UNSUPPORTED, "head outputs are read from d_pred");
         const Tensor& t = p.tensors[o.out];
         const int Ho = c->lastH >> t.level, Wo = c->lastW >> t.level, C = p.convs[o.conv].cout, B = c->lastB;

@@ -243,7 +243,7 @@ class YOLO(object):
             raise FileNotFoundError(weights)
         with open(weights, "rb") as fp:
             magic = fp.read(4)
-        if magic == b"CYW1":
+        if magic in (b"CYW1", b"CYW2"):
             return weights
         # an ultralytics checkpoint (scripts/run.py:347 passes the .pt path): converted once, without unpickling any of
         # its classes (pt_import), and cached next to the seeded files

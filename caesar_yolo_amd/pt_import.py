@@ -11,13 +11,15 @@ The reference hands the path straight to `ultralytics.YOLO(weights)` (scripts/ru
   * the placeholder graph is then flattened exactly like `nn.Module.state_dict()` (`_modules` / `_parameters` /
     `_buffers`), which yields the `model.N....conv.weight`, `...bn.running_mean` names that `weights.fold` consumes.
 
-Only the YOLOv8 detect architecture (Conv / C2f / SPPF / Upsample / Concat / Detect) is accepted; YOLO11 blocks
-(C3k2, C2PSA, depth-wise detect head) are recognised and refused with a clear message.
+Two detect architectures are accepted, recognised by their layer-class sequence: YOLOv8 (Conv / C2f / SPPF / Upsample /
+Concat / Detect) and YOLO11 (C3k2 / C2PSA / depth-wise class branch; yolo11_graph.py).  Anything else is refused with a
+clear message.
 No trained checkpoint ships with the reference (README.md:192-206 are links), so this importer is tested against a
 synthetic checkpoint of the same pickle structure written by the test-suite (tests/test_pt_import.py): parity with a
 real ultralytics file is unpinned.
 """
 import io
+import math
 import pickle
 import zipfile
 from collections import OrderedDict
@@ -32,7 +34,9 @@ _STORAGE_DTYPES = {
 }
 _YOLOV8_LAYERS = ["Conv", "Conv", "C2f", "Conv", "C2f", "Conv", "C2f", "Conv", "C2f", "SPPF", "Upsample", "Concat", "C2f",
                   "Upsample", "Concat", "C2f", "Conv", "Concat", "C2f", "Conv", "Concat", "C2f", "Detect"]
-_YOLO11_ONLY = ("C3k2", "C2PSA", "C3k", "PSABlock", "Attention", "DWConv", "C2fCIB", "SCDown", "PSA", "v10Detect")
+_YOLO11_LAYERS = ["Conv", "Conv", "C3k2", "Conv", "C3k2", "Conv", "C3k2", "Conv", "C3k2", "SPPF", "C2PSA", "Upsample", "Concat",
+                  "C3k2", "Upsample", "Concat", "C3k2", "Conv", "Concat", "C3k2", "Conv", "Concat", "C3k2", "Detect"]
+_UNSUPPORTED_BLOCKS = ("C2fCIB", "SCDown", "PSA", "v10Detect", "RepC3", "RTDETRDecoder", "Segment", "Pose", "OBB", "A2C2f")
 
 
 class PtImportError(Exception):
@@ -202,47 +206,24 @@ def _detect_scale(sd):
     raise PtImportError("stem width %d / depths do not match any YOLOv8 scale (n,s,m,l,x)" % w0.shape[0])
 
 
-def import_ultralytics_pt(path):
-    """-> (state_dict {name: fp32 ndarray} in ultralytics naming, names {int: str}, scale, nc).
+def _detect_scale11(sd):
+    from . import yolo11_graph as G
+    w0 = sd.get("model.0.conv.weight")
+    if w0 is None or w0.ndim != 4 or w0.shape[1] != 3:
+        raise PtImportError("model.0.conv.weight missing or not a 3-channel stem: not a YOLO11 detection checkpoint")
+    n_m2 = len({k.split(".")[3] for k in sd if k.startswith("model.2.m.")})
+    c3k_at_2 = any(k.startswith("model.2.m.0.cv3.") for k in sd)
+    for scale, (d, w, mc) in G.SCALES.items():
+        width = int(math.ceil(min(64, mc) * w / 8) * 8)
+        if width == w0.shape[0] and max(round(2 * d), 1) == n_m2 and (scale in "mlx") == c3k_at_2:
+            return scale
+    raise PtImportError("stem width %d / depth %d do not match any YOLO11 scale (n,s,m,l,x)" % (w0.shape[0], n_m2))
 
-    Accepts both un-fused checkpoints (Conv2d without bias + BatchNorm2d: what ultralytics saves after training) and
-    fused ones (Conv2d with bias, no bn)."""
-    ck = load_checkpoint_objects(path)
-    model = None
-    if isinstance(ck, dict):
-        model = ck.get("ema") if ck.get("ema") is not None else ck.get("model")
-        if model is None and all(isinstance(v, np.ndarray) for v in ck.values()) and len(ck):
-            model = None                                   # a bare state_dict
-    names = None
-    if model is not None and not isinstance(model, dict):
-        seq = _children(model).get("model")
-        if seq is None:
-            raise PtImportError("checkpoint 'model' has no .model Sequential: not an ultralytics detection model")
-        layers = [_class_name(m) for m in _children(seq).values()]
-        bad = sorted(set(l for l in layers if l in _YOLO11_ONLY))
-        if bad:
-            raise PtImportError("YOLO11/YOLOv10 blocks %s are not supported by the HIP detect path yet (YOLOv8 only)" % bad)
-        if layers != _YOLOV8_LAYERS:
-            raise PtImportError("layer sequence %s is not the YOLOv8 detect graph" % layers)
-        sd = state_dict_of(model)
-        names = getattr(model, "names", None)
-    else:
-        sd = OrderedDict((k, v) for k, v in (model if isinstance(model, dict) else ck).items() if isinstance(v, np.ndarray))
-        if not sd:
-            raise PtImportError("no tensors found in %s" % path)
-    sd = OrderedDict((k, np.ascontiguousarray(v, dtype=np.float32)) for k, v in sd.items() if v.dtype.kind == "f")
-    scale = _detect_scale(sd)
-    cls_last = [k for k in sd if k.startswith("model.22.cv3.0.2.weight")]
-    if not cls_last:
-        raise PtImportError("detect head (model.22.cv3) missing")
-    nc = int(sd[cls_last[0]].shape[0])
-    if isinstance(names, (list, tuple)):
-        names = {i: n for i, n in enumerate(names)}
-    if not isinstance(names, dict) or len(names) != nc:
-        names = {i: "class%d" % i for i in range(nc)}
-    names = {int(k): str(v) for k, v in names.items()}
-    # normalise fused checkpoints to the layout weights.fold expects (identity BatchNorm)
-    for cs in S.conv_list(scale, nc):
+
+def _fused_to_identity_bn(sd, convs):
+    """Fused checkpoints (Conv2d with bias, no bn) -> the layout fold() expects, with an identity BatchNorm."""
+    from .weights import BN_EPS
+    for cs in convs:
         if not cs.bn:
             if cs.name + ".weight" not in sd or cs.name + ".bias" not in sd:
                 raise PtImportError("missing %s.weight/.bias" % cs.name)
@@ -250,23 +231,88 @@ def import_ultralytics_pt(path):
         w = sd.get(cs.name + ".conv.weight")
         if w is None:
             raise PtImportError("missing %s.conv.weight" % cs.name)
-        if w.shape != (cs.cout, cs.cin, cs.k, cs.k):
-            raise PtImportError("%s.conv.weight has shape %s, expected %s" % (cs.name, w.shape, (cs.cout, cs.cin, cs.k, cs.k)))
+        groups = getattr(cs, "groups", 1)
+        if w.shape != (cs.cout, cs.cin // groups, cs.k, cs.k):
+            raise PtImportError("%s.conv.weight has shape %s, expected %s" % (cs.name, w.shape, (cs.cout, cs.cin // groups, cs.k, cs.k)))
         if cs.name + ".bn.weight" not in sd:
             b = sd.get(cs.name + ".conv.bias")
             if b is None:
                 raise PtImportError("%s has neither BatchNorm statistics nor a fused bias" % cs.name)
-            from .weights import BN_EPS
             sd[cs.name + ".bn.weight"] = np.full(cs.cout, np.sqrt(np.float32(1.0) + np.float32(BN_EPS)), np.float32)
             sd[cs.name + ".bn.bias"] = b.astype(np.float32)
             sd[cs.name + ".bn.running_mean"] = np.zeros(cs.cout, np.float32)
             sd[cs.name + ".bn.running_var"] = np.ones(cs.cout, np.float32)
-    return sd, names, scale, nc
+
+
+def import_pt(path):
+    """-> dict(sd={name: fp32 ndarray} in ultralytics naming, names={int: str}, scale, nc, arch='yolov8'|'yolo11').
+
+    Accepts both un-fused checkpoints (Conv2d without bias + BatchNorm2d: what ultralytics saves after training) and
+    fused ones (Conv2d with bias, no bn)."""
+    ck = load_checkpoint_objects(path)
+    model = None
+    if isinstance(ck, dict):
+        model = ck.get("ema") if ck.get("ema") is not None else ck.get("model")
+    names, arch = None, None
+    if model is not None and not isinstance(model, dict):
+        seq = _children(model).get("model")
+        if seq is None:
+            raise PtImportError("checkpoint 'model' has no .model Sequential: not an ultralytics detection model")
+        layers = [_class_name(m) for m in _children(seq).values()]
+        bad = sorted(set(l for l in layers if l in _UNSUPPORTED_BLOCKS))
+        if bad:
+            raise PtImportError("blocks %s are not supported by the HIP detect path (YOLOv8 and YOLO11 detection only)" % bad)
+        if layers == _YOLOV8_LAYERS:
+            arch = "yolov8"
+        elif layers == _YOLO11_LAYERS:
+            arch = "yolo11"
+        else:
+            raise PtImportError("layer sequence %s is neither the YOLOv8 nor the YOLO11 detect graph" % layers)
+        sd = state_dict_of(model)
+        names = getattr(model, "names", None)
+    else:
+        sd = OrderedDict((k, v) for k, v in (model if isinstance(model, dict) else ck).items() if isinstance(v, np.ndarray))
+        if not sd:
+            raise PtImportError("no tensors found in %s" % path)
+        arch = "yolo11" if any(k.startswith("model.23.") for k in sd) else "yolov8"
+    sd = OrderedDict((k, np.ascontiguousarray(v, dtype=np.float32)) for k, v in sd.items() if v.dtype.kind == "f")
+    head = "model.23" if arch == "yolo11" else "model.22"
+    cls_last = sd.get(head + ".cv3.0.2.weight")
+    if cls_last is None:
+        raise PtImportError("detect head (%s.cv3) missing" % head)
+    nc = int(cls_last.shape[0])
+    if isinstance(names, (list, tuple)):
+        names = {i: n for i, n in enumerate(names)}
+    if not isinstance(names, dict) or len(names) != nc:
+        names = {i: "class%d" % i for i in range(nc)}
+    names = {int(k): str(v) for k, v in names.items()}
+    if arch == "yolo11":
+        from . import yolo11_graph as G
+        scale = _detect_scale11(sd)
+        _fused_to_identity_bn(sd, G.build(scale, nc).convs)
+    else:
+        scale = _detect_scale(sd)
+        _fused_to_identity_bn(sd, S.conv_list(scale, nc))
+    return dict(sd=sd, names=names, scale=scale, nc=nc, arch=arch)
+
+
+def import_ultralytics_pt(path):
+    """YOLOv8 checkpoints: -> (state_dict, names, scale, nc)  (kept for callers that only handle YOLOv8)."""
+    r = import_pt(path)
+    if r["arch"] != "yolov8":
+        raise PtImportError("%s is a %s checkpoint; use import_pt / convert_pt_to_cyw" % (path, r["arch"]))
+    return r["sd"], r["names"], r["scale"], r["nc"]
 
 
 def convert_pt_to_cyw(pt_path, cyw_path):
-    """ultralytics `.pt` -> CYW1 file for cy_load_weights; returns (scale, names)."""
+    """ultralytics `.pt` -> CYW file for cy_load_weights (CYW1 for YOLOv8, CYW2 with the plan inside for YOLO11);
+    returns (scale, names)."""
     from . import weights as W
-    sd, names, scale, nc = import_ultralytics_pt(pt_path)
-    W.write_cyw(cyw_path, W.fold(sd, scale, nc), names, scale)
-    return scale, names
+    r = import_pt(pt_path)
+    if r["arch"] == "yolo11":
+        from . import yolo11_graph as G
+        g = G.build(r["scale"], r["nc"])
+        W.write_cyw2(cyw_path, g, W.fold_graph(r["sd"], g), r["names"])
+    else:
+        W.write_cyw(cyw_path, W.fold(r["sd"], r["scale"], r["nc"]), r["names"], r["scale"])
+    return r["scale"], r["names"]

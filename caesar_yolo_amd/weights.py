@@ -8,6 +8,12 @@
   (what ultralytics `fuse()` does before inference).
 * `write_cyw(path, ...)` / `read_cyw(path)` -- the flat "CYW1" file the C-ABI loads with `cy_load_weights`.
 
+CYW2 (write_cyw2) carries the execution plan as well -- tensors, ops and convolutions of a yolo11_graph.Graph -- so the
+runtime needs no built-in knowledge of the architecture:
+  "CYW2" u32 version=2 | char arch[8] | char scale[4] | u32 nc nnames ntensors nops nconv | u32 feat_level[3]
+  nnames x { u32 len | bytes (padded to 4) }      ntensors x { u32 level C }      nops x { i32 x 20 (yolo11_graph op fields) }
+  nconv  x { u32 cout cin k s act groups | u32 name_len | name (padded to 4) | f32 W[cout][cin/groups][k][k] | f32 b[cout] }
+
 CYW1 layout (little endian):
   "CYW1" u32 version=1 | char scale[4] | u32 nc | u32 nconv | u32 nnames
   nnames x { u32 len | bytes (padded to 4) }
@@ -180,15 +186,68 @@ def make_seeded_file(path, scale="l", nc=5, seed=20260104, names=None):
 
 
 def read_cyw_header(path):
-    """-> (scale, names dict, nc, nconv) without touching the tensor payload."""
+    """-> (scale, names dict, nc, nconv) without touching the tensor payload (CYW1 and CYW2)."""
     with open(path, "rb") as fp:
-        head = fp.read(24)
-        if head[:4] != b"CYW1":
-            raise ValueError("%s: not a CYW1 weight file" % path)
-        scale = head[8:12].rstrip(b"\0").decode()
-        nc, nconv, nnames = struct.unpack_from("<III", head, 12)
+        magic = fp.read(4)
+        if magic == b"CYW1":
+            head = magic + fp.read(20)
+            scale = head[8:12].rstrip(b"\0").decode()
+            nc, nconv, nnames = struct.unpack_from("<III", head, 12)
+        elif magic == b"CYW2":
+            head = fp.read(4 + 8 + 4 + 20 + 12)
+            scale = head[12:16].rstrip(b"\0").decode()
+            nc, nnames, _, _, nconv = struct.unpack_from("<IIIII", head, 16)
+        else:
+            raise ValueError("%s: not a CYW weight file" % path)
         names = {}
         for i in range(nnames):
             n, = struct.unpack("<I", fp.read(4))
             names[i] = fp.read((n + 3) // 4 * 4)[:n].decode()
     return scale, names, nc, nconv
+
+
+OP_FIELDS = ("kind", "conv", "in0", "in0_coff", "c0", "up0", "in1", "in1_coff", "c1", "out", "out_coff", "res", "res_coff",
+             "pred_level", "pred_coff", "p0", "p1", "p2", "p3", "_pad")
+
+
+def fold_graph(ck, graph):
+    """Conv(+BatchNorm eps 1e-3) folding over a yolo11_graph.Graph's conv list (grouped / depth-wise convs included:
+    the weight is [cout][cin/groups][k][k]) -> list of (ConvSpec, W, b) in state_dict order."""
+    out = []
+    for cs in graph.convs:
+        if cs.bn:
+            w = np.asarray(ck[cs.name + ".conv.weight"], np.float32)
+            g, beta = ck[cs.name + ".bn.weight"], ck[cs.name + ".bn.bias"]
+            mu, var = ck[cs.name + ".bn.running_mean"], ck[cs.name + ".bn.running_var"]
+            sc = (g / np.sqrt(var + np.float32(BN_EPS))).astype(np.float32)
+            wf = (w * sc[:, None, None, None]).astype(np.float32)
+            bf = (beta - mu * sc).astype(np.float32)
+        else:
+            wf = np.asarray(ck[cs.name + ".weight"], np.float32)
+            bf = np.asarray(ck[cs.name + ".bias"], np.float32)
+        if wf.shape != (cs.cout, cs.cin // cs.groups, cs.k, cs.k):
+            raise ValueError("%s: weight shape %s, expected %s" % (cs.name, wf.shape, (cs.cout, cs.cin // cs.groups, cs.k, cs.k)))
+        out.append((cs, np.ascontiguousarray(wf), np.ascontiguousarray(bf)))
+    return out
+
+
+def write_cyw2(path, graph, folded, names):
+    nc = len(names)
+    if nc != graph.nc:
+        raise ValueError("names (%d) do not match the graph's class count (%d)" % (nc, graph.nc))
+    with open(path, "wb") as fp:
+        fp.write(b"CYW2" + struct.pack("<I", 2) + graph.arch.encode().ljust(8, b"\0") + graph.scale.encode().ljust(4, b"\0"))
+        fp.write(struct.pack("<IIIII", nc, nc, len(graph.tensors), len(graph.ops), len(folded)))
+        fp.write(struct.pack("<III", *graph.feat_level))
+        for i in range(nc):
+            nb = str(names[i]).encode()
+            fp.write(struct.pack("<I", len(nb)) + _pad4(nb))
+        for lev, C in graph.tensors:
+            fp.write(struct.pack("<II", lev, C))
+        for o in graph.ops:
+            fp.write(struct.pack("<20i", *[int(o.get(k, 0)) for k in OP_FIELDS]))
+        for cs, w, b in folded:
+            nb = cs.name.encode()
+            fp.write(struct.pack("<IIIIIII", cs.cout, cs.cin, cs.k, cs.s, int(cs.act), cs.groups, len(nb)) + _pad4(nb))
+            fp.write(np.ascontiguousarray(w, "<f4").tobytes())
+            fp.write(np.ascontiguousarray(b, "<f4").tobytes())
