@@ -245,9 +245,9 @@ def scale_boxes(boxes, img1_hw, img0_hw):
 class OracleYOLO(object):
     """Stand-in for `ultralytics.YOLO(weights)`: `.names` and `__call__(img, imgsz=, conf=, iou=, **ignored)`."""
 
-    def __init__(self, weights, names, scale="l", threads=None):
+    def __init__(self, weights, names, scale="l", threads=None, net=None):
         self.names = dict(names)
-        self.net = Net(weights, scale, len(names))
+        self.net = net if net is not None else Net(weights, scale, len(names))      # net: e.g. yolo11_ref.Net11 (same head layout)
         if threads:
             torch.set_num_threads(threads)
 

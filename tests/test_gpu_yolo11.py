@@ -49,3 +49,30 @@ def test_yolo11_forward_matches_oracle(tmp_path, scale, prec, tol_raw, tol_tap):
         assert err <= tol_tap * sc, "%s: max abs err %.3e (scale %.2f)" % (name, err, sc)
     err = float((pred.cpu() - raw).abs().max())
     assert err <= tol_raw * max(1.0, float(raw.abs().max())), "raw head output: max abs err %.3e" % err
+
+
+def test_yolo11_model_call_end_to_end(tmp_path):
+    """The reference-shaped model call (`YOLO(weights)(image, imgsz=, conf=, iou=)`, caesar_yolo/evaluation.py:181-193) with a
+    YOLO11 weight file: LetterBox -> network -> decode -> NMS -> scale_boxes on the GPU (f32 context) against the oracle
+    (oracle/yolo11_ref.Net11 + the shared decode/NMS of oracle/yolov8_ref.py)."""
+    from caesar_yolo_amd import weights as W
+    from caesar_yolo_amd.model import YOLO
+    from oracle import yolo11_ref as O
+    from oracle import yolov8_ref as Y
+    nc, names = 3, {0: "a", 1: "b", 2: "c"}
+    g, wd = seeded_folded("n", nc, cls_bias=-1.5)
+    path = str(tmp_path / "y11n.cyw")
+    W.write_cyw2(path, g, [(cs, wd[cs.name][0], wd[cs.name][1]) for cs in g.convs], names)
+    model = YOLO(path, precision="fp32", max_batch=1, max_imgsz=256, device=0)
+    assert model.names == names and model.scale == "n"
+    oracle = Y.OracleYOLO(None, names, net=O.Net11(wd, "n", nc))
+    rng = np.random.default_rng(3)
+    img = rng.uniform(0, 255, (200, 230, 3))
+    got = model(img, imgsz=256, conf=0.3, iou=0.5)[0]
+    ref = oracle(img, imgsz=256, conf=0.3, iou=0.5)[0]
+    n = len(ref.boxes.conf)
+    assert 3 <= n <= 300, n
+    assert len(got.boxes.conf) == n
+    np.testing.assert_array_equal(got.boxes.cls.cpu().numpy().astype(int), ref.boxes.cls.numpy().astype(int))
+    np.testing.assert_allclose(got.boxes.conf.cpu().numpy(), ref.boxes.conf.numpy(), atol=1e-4)
+    np.testing.assert_allclose(got.boxes.xyxy.cpu().numpy(), ref.boxes.xyxy.numpy(), atol=256 * 1e-4)

@@ -20,8 +20,9 @@ class _Calibrating(O.Net11):
         return F.silu(y) if act else y
 
 
-def seeded_folded(scale, nc, seed=11, probe_hw=128):
-    """-> (graph, {conv name: (W, b)} folded fp32 numpy)."""
+def seeded_folded(scale, nc, seed=11, probe_hw=128, cls_bias=None):
+    """-> (graph, {conv name: (W, b)} folded fp32 numpy).  cls_bias: constant bias of the class-logit convs (negative ->
+    few candidates above the confidence threshold, like a trained detector)."""
     g = G.build(scale, nc)
     rng = np.random.default_rng(seed)
     wd = {}
@@ -34,4 +35,9 @@ def seeded_folded(scale, nc, seed=11, probe_hw=128):
     x = torch.from_numpy(rng.uniform(0, 1, (1, 3, probe_hw, probe_hw)).astype(np.float32))
     with torch.no_grad():
         net.forward(x)
-    return g, {k: (v[0].numpy().copy(), v[1].numpy().copy()) for k, v in net.w.items()}
+    out = {k: (v[0].numpy().copy(), v[1].numpy().copy()) for k, v in net.w.items()}
+    if cls_bias is not None:
+        for l in range(3):
+            k = "model.23.cv3.%d.2" % l
+            out[k] = (out[k][0], np.full_like(out[k][1], cls_bias))
+    return g, out
