@@ -76,3 +76,42 @@ def test_yolo11_model_call_end_to_end(tmp_path):
     np.testing.assert_array_equal(got.boxes.cls.cpu().numpy().astype(int), ref.boxes.cls.numpy().astype(int))
     np.testing.assert_allclose(got.boxes.conf.cpu().numpy(), ref.boxes.conf.numpy(), atol=1e-4)
     np.testing.assert_allclose(got.boxes.xyxy.cpu().numpy(), ref.boxes.xyxy.numpy(), atol=256 * 1e-4)
+
+
+def test_yolo11_tile_path(tmp_path):
+    """The batched tile entry (crop -> device preprocessing -> YOLO11 -> NMS -> IoU merge) with a CYW2 file: per-tile results
+    equal the CPU oracle's chain (numpy preprocessing, oracle/yolo11_ref network, shared NMS and process_detections)."""
+    from caesar_yolo_amd import weights as W
+    from caesar_yolo_amd import preprocessing as PP
+    from caesar_yolo_amd.model import YOLO
+    from gpu_common import ROOT
+    from oracle import yolo11_ref as O
+    from oracle import yolov8_ref as Y
+    from oracle import preprocessing_ref as P
+    from oracle import postproc_ref as R
+    nc, names = 3, {0: "a", 1: "b", 2: "c"}
+    conf, iou, soft, hard = 0.3, 0.5, 0.3, 0.8
+    g, wd = seeded_folded("n", nc, cls_bias=-1.5)
+    path = str(tmp_path / "y11n.cyw")
+    W.write_cyw2(path, g, [(cs, wd[cs.name][0], wd[cs.name][1]) for cs in g.convs], names)
+    model = YOLO(path, precision="fp32", max_batch=4, max_imgsz=256, device=0)
+    oracle = Y.OracleYOLO(None, names, net=O.Net11(wd, "n", nc))
+    img = np.load(os.path.join(ROOT, "tests/golden/mosaic_c.npz"))["img"].astype(np.float32)
+    mosaic = model.engine().mosaic_to_device(img)
+    cfg = PP.DataPreprocessor([PP.ZScaleTransformer([0.25] * 3), PP.MinMaxNormalizer(0, 255)]).program()
+    dp = P.build_pipeline([("zscale", dict(contrasts=[0.25] * 3)), ("minmax", dict(norm_min=0, norm_max=255))])
+    coords = [(0, 256, 0, 256), (256, 512, 0, 256), (128, 384, 128, 384), (600, 856, 400, 656)]
+    res = model.predict_tiles(mosaic, coords, cfg, imgsz=256, conf=conf, iou=iou,
+                              merge_overlap_iou_thr_soft=soft, merge_overlap_iou_thr_hard=hard)
+    total = 0
+    for (x0, x1, y0, y1), r in zip(coords, res):
+        im = dp(P.to_cube(np.array(img[y0:y1, x0:x1], np.float32)))
+        det, _, _, _ = oracle.predict_raw(im, 256, conf, iou)
+        kb, ks, kc = R.process_detections(det[:, :4].numpy(), det[:, 4].numpy(), det[:, 5].numpy(), conf, soft, hard)[:3]
+        assert r is not None and len(r.boxes.conf) == len(ks)
+        total += len(ks)
+        if len(ks):
+            np.testing.assert_allclose(r.boxes.conf.cpu().numpy(), ks, atol=1e-4)
+            np.testing.assert_array_equal(r.boxes.cls.cpu().numpy().astype(int), np.asarray(kc).astype(int))
+            np.testing.assert_allclose(r.boxes.xyxy.cpu().numpy(), kb, atol=256 * 1e-4)
+    assert total >= 4
