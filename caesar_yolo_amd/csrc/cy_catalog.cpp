@@ -8,6 +8,7 @@
 // sources of neighbouring tiles.  Component order, survivor choice and naming order are the reference's.
 #include "../../include/caesar_yolo_hip.h"
 #include <algorithm>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -73,13 +74,30 @@ const std::vector<std::vector<int>>& cached_neighbor_lists(const int* tiles, int
     }
     return lists;
 }
+// Run f(lo, hi) over [0, n) on a few host threads (the two loops below are independent per element; at N GPUs this merge is
+// the serial tail of the step on rank 0, so its 1-2 ms matter).  Small inputs stay on the calling thread.
+template <typename F>
+void parallel_ranges(int n, int min_per_thread, F f) {
+    int nt = (int)std::thread::hardware_concurrency();
+    if (nt > 8) nt = 8;
+    if (nt < 1) nt = 1;
+    if (n / (min_per_thread > 0 ? min_per_thread : 1) < nt) nt = n / (min_per_thread > 0 ? min_per_thread : 1);
+    if (nt <= 1) { f(0, n, 0); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t) {
+        const int lo = (int)((long)n * t / nt), hi = (int)((long)n * (t + 1) / nt);
+        th.emplace_back([=]() { f(lo, hi, t); });
+    }
+    for (auto& x : th) x.join();
+}
 }  // namespace
 
 extern "C" int cy_make_tile_records(const float* det, const int* det_tile, int n, const int* tiles, int T, double* rec) {
     if (n < 0 || T < 1 || (n > 0 && (!det || !det_tile || !rec)) || !tiles) return CY_ERR_ARG;
     for (int i = 0; i < n; ++i) if (det_tile[i] < 0 || det_tile[i] >= T) return CY_ERR_ARG;
     const auto& nb = cached_neighbor_lists(tiles, T);
-    for (int i = 0; i < n; ++i) {
+    parallel_ranges(n, 2048, [&](int lo, int hi, int) {
+    for (int i = lo; i < hi; ++i) {
         const int t = det_tile[i];
         const int* tc = tiles + 4 * t;
         const int nx = tc[1] - tc[0], ny = tc[3] - tc[2];
@@ -101,6 +119,7 @@ extern "C" int cy_make_tile_records(const float* det, const int* det_tile, int n
         r[0] = gx1; r[1] = gy1; r[2] = gx2; r[3] = gy2; r[4] = (double)det[6 * i + 4]; r[5] = (double)(int)det[6 * i + 5];
         r[6] = t; r[7] = edge;
     }
+    });
     return CY_OK;
 }
 
@@ -130,24 +149,30 @@ extern "C" int cy_merge_edge_sources(const double* rec, int n, const int* tiles,
     std::vector<double> box(4 * (size_t)N);       // compact copy of the edge sources' boxes (cache-friendly pair loop)
     std::vector<int> tof(N);
     for (int k = 0; k < N; ++k) { const double* r = rec + 8 * tbm[k]; box[4 * k] = r[0]; box[4 * k + 1] = r[1]; box[4 * k + 2] = r[2]; box[4 * k + 3] = r[3]; tof[k] = (int)r[6]; }
-    pairs.reserve(N);
-    for (int i = 0; i < N; ++i) {
-        const double ax1 = box[4 * i], ay1 = box[4 * i + 1], ax2 = box[4 * i + 2], ay2 = box[4 * i + 3];
-        const int ti = tof[i];
-        for (int tj : nb[ti]) {                   // tid_j in neighborTileIds(tile_i): a tile is never its own neighbour
-            if (tj < ti) continue;                // j > i implies tile_j >= tile_i
-            // a source lies inside its tile's inclusive bounds (cy_make_tile_records), so a box that misses tile tj misses
-            // every source of tile tj: skips most of the eight neighbours without touching their sources
-            const int* q = tiles + 4 * tj;
-            if (ax2 < q[0] || ax1 > q[1] || ay2 < q[2] || ay1 > q[3]) continue;
-            for (int j = tstart[tj]; j < tstart[tj + 1]; ++j) {
-                if (j <= i) continue;
-                const double* b = &box[4 * j];
-                if (ax2 < b[0] || ax1 > b[2] || ay2 < b[1] || ay1 > b[3]) continue;
-                pairs.push_back({i, j}); deg[i + 1]++; deg[j + 1]++;
+    // ranges of i on a few threads, each with its own pair list; concatenated in range order they are in the same
+    // lexicographic order a single loop produces
+    std::vector<std::vector<std::pair<int, int>>> part(8);
+    parallel_ranges(N, 1024, [&](int lo, int hi, int slot) {
+        auto& out_pairs = part[slot];
+        for (int i = lo; i < hi; ++i) {
+            const double ax1 = box[4 * i], ay1 = box[4 * i + 1], ax2 = box[4 * i + 2], ay2 = box[4 * i + 3];
+            const int ti = tof[i];
+            for (int tj : nb[ti]) {               // tid_j in neighborTileIds(tile_i): a tile is never its own neighbour
+                if (tj < ti) continue;            // j > i implies tile_j >= tile_i
+                // a source lies inside its tile's inclusive bounds (cy_make_tile_records), so a box that misses tile tj
+                // misses every source of tile tj: skips most of the eight neighbours without touching their sources
+                const int* q = tiles + 4 * tj;
+                if (ax2 < q[0] || ax1 > q[1] || ay2 < q[2] || ay1 > q[3]) continue;
+                for (int j = tstart[tj]; j < tstart[tj + 1]; ++j) {
+                    if (j <= i) continue;
+                    const double* b = &box[4 * j];
+                    if (ax2 < b[0] || ax1 > b[2] || ay2 < b[1] || ay1 > b[3]) continue;
+                    out_pairs.push_back({i, j});
+                }
             }
         }
-    }
+    });
+    for (auto& v : part) for (auto& pr : v) { pairs.push_back(pr); deg[pr.first + 1]++; deg[pr.second + 1]++; }
     for (int v = 0; v < N; ++v) deg[v + 1] += deg[v];
     std::vector<int> adjv(pairs.size() * 2), fill(deg.begin(), deg.end() - 1);
     for (auto& pr : pairs) { adjv[fill[pr.first]++] = pr.second; adjv[fill[pr.second]++] = pr.first; }
