@@ -755,9 +755,14 @@ static hipError_t launch_pp(const ConvArgs& a, hipStream_t s) {
 // (measured: 16 rounds x ~10 us).  Here a workgroup is persistent: the whole 64 x (9 x 64) weight panel is staged in LDS
 // ONCE (72 KB), next to a double-buffered input halo (2 x 42 KB), and the nine taps of a patch run without any barrier; the halo of the next patch streams in (LDS-DMA) under the current patch's MFMAs and
 // stores.  One barrier per patch.
+// KC = input channels (64, or 32 with 64-byte LDS rows and the 64-byte-chunk weight copy: the 32-channel bottlenecks of the
+// n/s scales and of YOLO11's C3k blocks; the output side still walks all 64 packed rows, half of them zero for Cout = 32).
+template <int KC>
 __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const ConvArgs a) {
     constexpr int TH = 16, TW = 16, NW = 4, NI = 4;      // 4 waves, one per SIMD, each 64 px x 64 ch with the full register file
-    constexpr int PR = (TH + 2) * (TW + 2), NWI = (PR + 7) / 8, PROUNDS = (NWI + NW - 1) / NW;
+    constexpr int RB = KC * 2, RPP = 1024 / RB, NCH = KC / 8, KK = KC / 32;     // row bytes, rows per 1 KiB DMA piece, 16-byte chunks per row
+    constexpr int PR = (TH + 2) * (TW + 2), NWI = (PR + RPP - 1) / RPP, PROUNDS = (NWI + NW - 1) / NW;
+    auto swz = [](int chunk, int row) { return KC == 64 ? (chunk ^ (row & 7)) : (chunk ^ (((row >> 2) & 1) << 1)); };
     constexpr int P_BYTES = (NWI + 1) * 1024;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) void lds_void;
@@ -771,17 +776,18 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const ConvArgs a) {
     const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in0), 0, a.in0_bytes, 0x00020000);
 
     // ---- weights -> LDS once: [tap][64 rows][128 B], same source-side swizzle as every other tile image
-    constexpr int W_BYTES = 9 * 64 * 128;
+    constexpr int W_BYTES = 9 * 64 * RB, WPIECES = W_BYTES / 1024, PPT = 64 / RPP;      // pieces per tap
     char* const Wl = smem;
     char* const Pl = smem + W_BYTES;
     {
-        const auto rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wgt), 0, a.wgt_bytes, 0x00020000);
+        const auto rsw = KC == 64 ? __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wgt), 0, a.wgt_bytes, 0x00020000)
+                                  : __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wgt32), 0, a.wgt32_bytes, 0x00020000);
 #pragma unroll
-        for (int j = 0; j < 18; ++j) {
-            const int pc = j * NW + wave;                   // 72 pieces of 8 rows: piece = tap*8 + row block
-            const int tap = pc >> 3, row = (pc & 7) * 8 + (lane >> 3);
-            const int q = (lane & 7) ^ (row & 7);
-            const unsigned off = (unsigned)((tap * 128 + row) * 128 + q * 16);        // slab-major packing, rows padded to 128, one K chunk
+        for (int j = 0; j < WPIECES / NW; ++j) {
+            const int pc = j * NW + wave;                   // pieces of RPP rows: piece = tap*PPT + row block
+            const int tap = pc / PPT, row = (pc % PPT) * RPP + lane / NCH;
+            const int q = swz(lane % NCH, row);
+            const unsigned off = (unsigned)((tap * 128 + row) * RB + q * 16);         // slab-major packing, rows padded to 128, one K chunk
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)(Wl + pc * 1024), 16, off, 0, 0, 0);
         }
     }
@@ -796,10 +802,10 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < PROUNDS; ++j) {
             const int wi = j * NW + wave;
-            const int r = wi * 8 + (lane >> 3);
+            const int r = wi * RPP + lane / NCH;
             const int ry = r / (TW + 2), rx = r - ry * (TW + 2);
             const int y = y0 + ry - 1, x = x0 + rx - 1;
-            const int q = (lane & 7) ^ (r & 7);
+            const int q = swz(lane % NCH, r);
             const bool ok = r < PR && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
             const unsigned off = ok ? (unsigned)(((b * H + y) * W + x) * a.in0_ct + a.in0_coff + q * 8) * 2u : CY_OOB;
             char* dst = Pl + buf * P_BYTES + (wi < NWI ? wi : NWI) * 1024;
@@ -821,20 +827,20 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const ConvArgs a) {
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // 18 groups (tap, kk) of 8 fragment reads + 16 MFMAs.  With ONE wave per SIMD nothing else hides the LDS latency,
+        // 9*KK groups (tap, kk) of 8 fragment reads + 16 MFMAs.  With ONE wave per SIMD nothing else hides the LDS latency,
         // so the fragments are double-buffered in registers: group g+1 is read before the MFMAs of group g are issued
         // (fences keep that order; the workgroup has 512 VGPRs per lane to spend).
         f16x8 xa[2][4], wb[2][NI];
         auto load_group = [&](int g, f16x8* x, f16x8* w) {
-            const int tap = g >> 1, kk = g & 1, kh = tap / 3, kw = tap - kh * 3, qf = fq + 4 * kk;
+            const int tap = g / KK, kk = g % KK, kh = tap / 3, kw = tap - kh * 3, qf = fq + 4 * kk;
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
                 const int r = (wm * 4 + mi + kh) * (TW + 2) + kw + fr;
-                x[mi] = *reinterpret_cast<const f16x8*>(P + r * 128 + ((qf ^ (r & 7)) << 4));
+                x[mi] = *reinterpret_cast<const f16x8*>(P + r * RB + (swz(qf, r) << 4));
             }
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
-                w[ni] = *reinterpret_cast<const f16x8*>(Wl + (tap * 64 + ni * 16 + fr) * 128 + ((qf ^ (fr & 7)) << 4));
+                w[ni] = *reinterpret_cast<const f16x8*>(Wl + (tap * 64 + ni * 16 + fr) * RB + (swz(qf, fr) << 4));
         };
         // residual of this patch: requested now, used in the epilogue (its latency hides under the 288 MFMAs)
         const int tx = pidx % tiles_x, ty = (pidx / tiles_x) % tiles_y, b = pidx / (tiles_x * tiles_y);
@@ -852,8 +858,8 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const ConvArgs a) {
         }
         load_group(0, xa[0], wb[0]);
 #pragma unroll
-        for (int g = 0; g < 18; ++g) {
-            if (g + 1 < 18) load_group(g + 1, xa[(g + 1) & 1], wb[(g + 1) & 1]);
+        for (int g = 0; g < 9 * KK; ++g) {
+            if (g + 1 < 9 * KK) load_group(g + 1, xa[(g + 1) & 1], wb[(g + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
@@ -908,17 +914,18 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const ConvArgs a) {
     }
 }
 
+template <int KC>
 static hipError_t launch_c64(const ConvArgs& a, hipStream_t s) {
-    constexpr int NWI = (18 * 18 + 7) / 8;
-    const size_t lds = 9 * 64 * 128 + 2 * (NWI + 1) * 1024;
+    constexpr int RPP = 1024 / (KC * 2), NWI = (18 * 18 + RPP - 1) / RPP;
+    const size_t lds = 9 * 64 * KC * 2 + 2 * (NWI + 1) * 1024;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_kernel<KC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const int npatch = a.B * ((a.Hi + 15) / 16) * ((a.Wi + 15) / 16);
     const int grid = npatch < 256 ? npatch : 256;                                  // one persistent workgroup per CU
-    hipLaunchKernelGGL(conv3x3_c64_kernel, dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(conv3x3_c64_kernel<KC>, dim3(grid), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 
@@ -1615,7 +1622,7 @@ static const char* const kVariantNames[CONV_NUM_VARIANTS] = {
     "conv_igemm_kernel<2,2,4> generic 128x128", "conv_igemm_kernel<4,1,2> generic 128x64",
     "conv3x3_halo2_kernel 3x3 s1 16x16px x128ch (halo<2,2> for odd slab counts)", "conv3x3_pp_kernel<2> 3x3 s1 16x16px x64ch",
     "conv3x3_pp_kernel<4> 3x3 s1 16x16px x128ch", "conv3x3_halo_kernel<4,*> 3x3 s1 16x16px x128ch",
-    "conv3x3_c64_kernel 3x3 s1 64->64 persistent", "conv_igemm_kernel<4,2,4,3> generic 256x128, 3-slab ring",
+    "conv3x3_c64_kernel<64|32> 3x3 s1 persistent, Cin 64 or 32", "conv_igemm_kernel<4,2,4,3> generic 256x128, 3-slab ring",
     "conv3x3_wide_kernel 3x3 s1 16x32px x128ch, K slabs of 32",
     "conv1x1_direct_kernel<4,2> 1x1 256px x256ch, pixels to regs", "conv1x1_direct_kernel<2,2> 1x1 256px x128ch, pixels to regs",
     "conv3x3_wide_kernel<WN=1> 3x3 s1 16x32px x64ch"};
@@ -1628,6 +1635,9 @@ int conv_variant(Precision p, const ConvArgs& a) {
     // 3x3 stride-1 layers (fp16 context; the fp32 parity context keeps the generic kernel): halo-reuse kernels.
     //   Cout <= 64  : ping-pong kernel with 64-channel tiles (256 px x 64 ch per workgroup)
     //   Cout >= 128 : 8x16-pixel patches x 128 channels, two workgroups per CU
+    if (p == PREC_F16 && a.k == 3 && a.s == 1 && a.c1 == 0 && !a.up0 && !a.out_f32 && a.Cin == 32 && narrow && a.wgt32 &&
+        a.out_bs == a.Ho * a.Wo && a.out_ro == 0)
+        return CONV_C64_PERSIST;                             // 32-channel variant of the persistent kernel
     if (p == PREC_F16 && a.k == 3 && a.s == 1 && a.c1 == 0 && !a.up0 && !a.out_f32 && a.Cin % 64 == 0 &&
         a.out_bs == a.Ho * a.Wo && a.out_ro == 0) {
         static const int force = getenv("CY_HALO_WM") ? atoi(getenv("CY_HALO_WM")) : 0;     // tuning override
@@ -1665,7 +1675,7 @@ int conv_variant(Precision p, const ConvArgs& a) {
 
 hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s) {
     switch (conv_variant(p, a)) {
-        case CONV_C64_PERSIST: return launch_c64(a, s);
+        case CONV_C64_PERSIST: return a.Cin == 32 ? launch_c64<32>(a, s) : launch_c64<64>(a, s);
         case CONV_PP_64: return launch_pp<2>(a, s);
         case CONV_PP_128: { ConvArgs b2 = a; b2.dbg = getenv("CY_DBG") ? atoi(getenv("CY_DBG")) : 0; return launch_pp<4>(b2, s); }
         case CONV_HALO16_128: return (getenv("CY_HALO_WM") && atoi(getenv("CY_HALO_WM")) == 43) ? launch_halo<4, 3>(a, s) : launch_halo<4, 2>(a, s);

@@ -215,7 +215,7 @@ int upload_weights(cy_ctx* c, const void* buf, size_t nbytes) {
         pack_weights(c->prec, W, co, ci, k, packed.data());
         HIPCHK(c, hipMalloc(&dc.w, dc.wbytes));
         HIPCHK(c, hipMemcpy(dc.w, packed.data(), dc.wbytes, hipMemcpyHostToDevice));
-        if (c->prec == PREC_F16 && k == 3 && s == 1 && ci % 64 == 0 && co >= 33) {   // second copy for conv3x3_wide_kernel
+        if (c->prec == PREC_F16 && k == 3 && s == 1 && ((ci % 64 == 0 && co >= 33) || (ci == 32 && co <= 64))) {   // second copy (64-byte K chunks) for conv3x3_wide_kernel / conv3x3_c64_kernel<32>
             dc.w32bytes = packed_weight_bytes(c->prec, co, ci, k, 64);
             packed.resize(dc.w32bytes);
             pack_weights(c->prec, W, co, ci, k, packed.data(), 64);
@@ -594,7 +594,7 @@ int cy_conv_bn_silu(cy_ctx* c, const void* d_in, int B, int Hi, int Wi, int Cin,
     HIPCHK(c, hipMemcpy(dw, packed.data(), wb, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(db, bias.data(), 4 * cp, hipMemcpyHostToDevice));
     void* dw32 = nullptr; size_t wb32 = 0;
-    if (c->prec == PREC_F16 && k == 3 && s == 1 && Cin % 64 == 0 && Cout >= 33) {
+    if (c->prec == PREC_F16 && k == 3 && s == 1 && ((Cin % 64 == 0 && Cout >= 33) || (Cin == 32 && Cout <= 64))) {
         wb32 = packed_weight_bytes(c->prec, Cout, Cin, k, 64);
         std::vector<char> p32(wb32);
         pack_weights(c->prec, h_w, Cout, Cin, k, p32.data(), 64);

@@ -34,6 +34,8 @@ CASES = [  # B, H, W, Cin, Cout, k, s, act, residual
     (2, 40, 64, 256, 192, 3, 1, True, True),      # 512-px wide kernel: ragged rows, Cout 192 (half-empty channel tile), residual, 4 slab pairs
     (1, 16, 32, 128, 128, 3, 1, False, False),    # wide kernel: a single patch, two slab pairs, no activation
     (3, 30, 60, 64, 256, 3, 1, True, False),      # wide kernel: ragged columns (60 of 64) and rows, one slab pair
+    (6, 64, 64, 32, 32, 3, 1, True, True),        # persistent kernel, 32-channel variant (64-byte LDS rows), residual
+    (3, 40, 50, 32, 64, 3, 1, True, False),       # 32 -> 64 channels, ragged patches
     (40, 32, 64, 128, 64, 3, 1, True, False),     # 64-channel variant of the wide kernel (box head), two slab pairs
     (16, 128, 128, 128, 128, 3, 2, True, False),  # pixels-direct kernel, 3x3 stride 2 (taps as uniform address shifts), 128-ch tile
     (5, 130, 126, 128, 320, 3, 2, True, False),   # pixels-direct 3x3 s2: odd rows/cols at the border, ragged 256-ch tiles, 18 K chunks
