@@ -1659,7 +1659,7 @@ int conv_variant(Precision p, const ConvArgs& a) {
     // 1x1: pixels-direct kernel once there is at least one 256-pixel tile per CU (below that the 128x128 tiles of the generic
     // kernel fill the chip better).  CY_DIRECT_MIN_BLOCKS is read per call so that the parity tests can force the path.
     if (p == PREC_F16 && !a.out_f32 && a.Cin % 64 == 0 &&
-        ((a.k == 1 && a.s == 1 && (a.c1 == 0 || a.c0 % 64 == 0)) || (a.k == 3 && a.s == 2 && a.c1 == 0 && !a.up0 && a.Cin >= 128 && s2_direct()))) {
+        ((a.k == 1 && a.s == 1 && (a.c1 == 0 || a.c0 % 64 == 0)) || (a.k == 3 && a.s == 2 && a.c1 == 0 && !a.up0 && (a.Cin >= 128 || pad64(a.Cout) < 256) && s2_direct()))) {
         const char* e = getenv("CY_DIRECT_MIN_BLOCKS");
         const long min_blocks = e ? atol(e) : 256;
         const int bn = pad64(a.Cout) >= 256 ? 256 : 128;
@@ -1689,7 +1689,8 @@ hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s) {
         case CONV_WIDE_128: return launch_wide<2>(a, s);
         case CONV_WIDE_64: return launch_wide<1>(a, s);
         case CONV_DIRECT_256: return a.k == 3 ? launch_direct<4, 2, 3, true>(a, s) : launch_direct<4, 2, 3, false>(a, s);
-        case CONV_DIRECT_128: return a.k == 3 ? launch_direct<2, 2, 4, true>(a, s) : launch_direct<2, 2, 4, false>(a, s);
+        case CONV_DIRECT_128:     // strided 3x3 (model.1): 64 px per wave, so every weight fragment feeds four MFMAs (-8 % vs 32 px)
+            return a.k == 3 ? launch_direct<2, 4, 2, true>(a, s) : launch_direct<2, 2, 4, false>(a, s);
         case CONV_GENERIC_64: return p == PREC_F16 ? launch_t<f16, 4, 1, 2>(a, s) : launch_t<float, 4, 1, 2>(a, s);
         default: return p == PREC_F16 ? launch_t<f16, 2, 2, 4>(a, s) : launch_t<float, 2, 2, 4>(a, s);
     }
