@@ -8,6 +8,7 @@
 // sources of neighbouring tiles.  Component order, survivor choice and naming order are the reference's.
 #include "../../include/caesar_yolo_hip.h"
 #include <algorithm>
+#include <cstdlib>
 #include <thread>
 #include <vector>
 
@@ -78,8 +79,9 @@ const std::vector<std::vector<int>>& cached_neighbor_lists(const int* tiles, int
 // the serial tail of the step on rank 0, so its 1-2 ms matter).  Small inputs stay on the calling thread.
 template <typename F>
 void parallel_ranges(int n, int min_per_thread, F f) {
+    static const int cap = getenv("CY_MERGE_THREADS") ? atoi(getenv("CY_MERGE_THREADS")) : 4;
     int nt = (int)std::thread::hardware_concurrency();
-    if (nt > 8) nt = 8;
+    if (nt > cap) nt = cap;
     if (nt < 1) nt = 1;
     if (n / (min_per_thread > 0 ? min_per_thread : 1) < nt) nt = n / (min_per_thread > 0 ? min_per_thread : 1);
     if (nt <= 1) { f(0, n, 0); return; }

@@ -121,6 +121,7 @@ class TileEngine(object):
         self.conf, self.iou, self.soft, self.hard = float(conf), float(iou), float(soft), float(hard)
         self.rank, self.world, self.batch = rank, world, min(int(batch), detector.max_batch)
         parts = partition_tiles(self.grid, self.imgsz, world, self.batch)
+        self._parts, self._perm = parts, None
         self.counts = [sum(len(t) for _, t in p) for p in parts]
         self.cap_tiles = max(max(self.counts), 1)
         self.my = parts[rank]
@@ -187,22 +188,30 @@ class TileEngine(object):
         x1,y1,x2,y2,score,class_id,edge,merged in catalog order, stats).  Valid rows are compacted on device first, so
         only the detections themselves cross PCIe."""
         g = self.gathered
-        valid = torch.zeros(g.shape[:2], dtype=torch.bool, device=g.device)
-        for r, n in enumerate(self.counts):
-            valid[r, :n] = True
-        rows = g[valid]                                            # [T, 1803]
-        tid = rows[:, -1].long()
-        rows = rows[torch.argsort(tid, stable=True)]
-        cnt, status, tid = rows[:, -3].long(), rows[:, -2].long(), rows[:, -1].long()
-        cnt = torch.where(status == 0, cnt, torch.zeros_like(cnt))
+        if getattr(self, "_perm", None) is None:
+            # the partition is deterministic: which (rank, row) holds which tile is known on every rank without looking at
+            # the data, so "valid rows in tile-id order" is ONE precomputed gather index
+            where = {}
+            for r, part in enumerate(self._parts):
+                row = 0
+                for _, tids in part:
+                    for t in tids:
+                        where[t] = r * g.shape[1] + row
+                        row += 1
+            self._perm = torch.tensor([where[t] for t in sorted(where)], dtype=torch.int64, device=g.device)
+            self._tid_sorted = np.array(sorted(where), np.int32)
+        rows = g.reshape(-1, g.shape[-1]).index_select(0, self._perm)              # [T, 1803] in tile-id order
+        meta = rows[:, -3:-1].cpu().numpy()                                        # (count, status) per tile: one small D2H
+        status_h = meta[:, 1].astype(np.int64)
+        cnt_h = np.where(status_h == 0, meta[:, 0].astype(np.int64), 0)
+        cnt = torch.from_numpy(cnt_h).to(g.device, non_blocking=True)
         keep = torch.arange(L.CY_MAX_DET, device=g.device)[None, :] < cnt[:, None]
         det = rows[:, :L.CY_MAX_DET * 6].reshape(-1, L.CY_MAX_DET, 6)[keep]          # [Ndet, 6] in tile-id order
-        dtile = torch.repeat_interleave(tid, cnt)
-        stats = {"tiles": int(rows.shape[0]), "skipped": int((status != 0).sum()), "per_tile_detections": int(cnt.sum())}
+        stats = {"tiles": int(rows.shape[0]), "skipped": int((status_h != 0).sum()), "per_tile_detections": int(cnt_h.sum())}
         import time as _t
         t0 = _t.time()
         det_h = np.ascontiguousarray(det.cpu().numpy(), np.float32)
-        dtile_h = np.ascontiguousarray(dtile.cpu().numpy().astype(np.int32))
+        dtile_h = np.ascontiguousarray(np.repeat(self._tid_sorted, cnt_h))
         t1 = _t.time()
         if getattr(self, "_tiles_np", None) is None:              # the grid as the C-ABI wants it, converted once
             self._tiles_np = np.ascontiguousarray(np.array(self.grid, np.int32).reshape(-1, 4))
