@@ -88,7 +88,8 @@ __device__ __forceinline__ bool iou_gt(float ix1, float iy1, float ix2, float iy
     return ovr > thr;
 }
 
-__global__ __launch_bounds__(256) void nms_kernel(const NmsArgs a, int cap_pow2) {
+constexpr int NMS_NT = 1024, NMS_NW = NMS_NT / 64;    // the sort and the kept-list test use every wave; the in-order resolution is wave 0's
+__global__ __launch_bounds__(NMS_NT) void nms_kernel(const NmsArgs a, int cap_pow2) {
     extern __shared__ __attribute__((aligned(16))) uint64_t lkeys[];      // NMS_LDS_KEYS entries (launch_nms)
     __shared__ float kx1[MAXDET], ky1[MAXDET], kx2[MAXDET], ky2[MAXDET], kar[MAXDET];
     __shared__ int kslot[MAXDET];
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256) void nms_kernel(const NmsArgs a, int cap_pow2)
     uint64_t* keys = np2 <= NMS_LDS_KEYS ? lkeys : a.keys + (size_t)b * cap_pow2;
     const float* cand = a.cand + (size_t)b * a.cap * 6;
     const int* canch = a.cand_anchor + (size_t)b * a.cap;
-    for (int i = tid; i < np2; i += 256) {
+    for (int i = tid; i < np2; i += NMS_NT) {
         uint64_t k = ~0ull;
         if (i < n) {
             const unsigned sb = __float_as_uint(cand[i * 6 + 4]);            // scores are positive: bit order = value order
@@ -112,22 +113,20 @@ __global__ __launch_bounds__(256) void nms_kernel(const NmsArgs a, int cap_pow2)
     __syncthreads();
     for (int kk = 2; kk <= np2; kk <<= 1)
         for (int j = kk >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < np2; i += 256) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const bool up = (i & kk) == 0;
-                    const uint64_t x = keys[i], y = keys[ixj];
-                    if ((x > y) == up) { keys[i] = y; keys[ixj] = x; }
-                }
+            for (int p = tid; p < (np2 >> 1); p += NMS_NT) {   // thread -> compare-exchange pair (i, i | j): every thread has work
+                const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1)), ixj = i | j;
+                const bool up = (i & kk) == 0;
+                const uint64_t x = keys[i], y = keys[ixj];
+                if ((x > y) == up) { keys[i] = y; keys[ixj] = x; }
             }
             __syncthreads();
         }
     if (n > MAX_NMS) n = MAX_NMS;
     // ---- scan in score order, 64 candidates per round.  The test of a round's candidates against the boxes kept so far is
-    // split over the four waves (wave w takes kept boxes w, w+4, ...: the dense tiles that set this kernel's duration have
+    // split over the sixteen waves (wave w takes kept boxes w, w+16, ...: the dense tiles that set this kernel's duration have
     // thousands of candidates against up to 300 kept boxes); wave 0 then resolves the round's survivors among themselves
     // in order, exactly as a one-wave scan would.
-    __shared__ unsigned long long amask[4];
+    __shared__ unsigned long long amask[NMS_NW];
     __shared__ int s_nk;
     const int lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_nk = 0;
@@ -146,11 +145,11 @@ __global__ __launch_bounds__(256) void nms_kernel(const NmsArgs a, int cap_pow2)
             area = (x2 - x1) * (y2 - y1);
         }
         bool alive = valid;
-        for (int t = wave; t < nk; t += 16) {                // four kept boxes per trip: their LDS reads are in flight together
+        for (int t = wave; t < nk; t += 4 * NMS_NW) {        // four kept boxes per trip: their LDS reads are in flight together
             float qx1[4], qy1[4], qx2[4], qy2[4], qar[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int tt = t + 4 * q;
+                const int tt = t + NMS_NW * q;
                 const bool in = tt < nk;                     // past the list: an empty box (intersection 0 -> never suppresses)
                 qx1[q] = in ? kx1[tt] : 0.0f; qy1[q] = in ? ky1[tt] : 0.0f; qx2[q] = in ? kx2[tt] : 0.0f; qy2[q] = in ? ky2[tt] : 0.0f;
                 qar[q] = in ? kar[tt] : 0.0f;
@@ -164,7 +163,9 @@ __global__ __launch_bounds__(256) void nms_kernel(const NmsArgs a, int cap_pow2)
         if (lane == 0) amask[wave] = mw;
         __syncthreads();
         if (wave == 0) {
-            unsigned long long m = amask[0] & amask[1] & amask[2] & amask[3];
+            unsigned long long m = amask[0];
+#pragma unroll
+            for (int w = 1; w < NMS_NW; ++w) m &= amask[w];
             alive = (m >> lane) & 1ull;
             while (m != 0ull && nk < a.max_det) {
                 const int j = __ffsll((long long)m) - 1;    // lowest alive lane = next kept box (wave-uniform)
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(256) void nms_kernel(const NmsArgs a, int cap_pow2)
     }
     // ---- emit: undo the letterbox (scale_boxes + clip_boxes) on the un-offset boxes, in kept (= score) order
     if (tid == 0) a.det_count[b] = nk;
-    for (int t = tid; t < nk; t += 256) {
+    for (int t = tid; t < nk; t += NMS_NT) {
         const float* c = cand + kslot[t] * 6;
         float bx1 = (c[0] - (float)a.padw) / a.gain, by1 = (c[1] - (float)a.padh) / a.gain;
         float bx2 = (c[2] - (float)a.padw) / a.gain, by2 = (c[3] - (float)a.padh) / a.gain;
@@ -206,7 +207,7 @@ hipError_t launch_nms(const NmsArgs& a, hipStream_t s) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds + 16384);
         attr_set = true;
     }
-    hipLaunchKernelGGL(nms_kernel, dim3(a.B), dim3(256), lds, s, a, cp2);
+    hipLaunchKernelGGL(nms_kernel, dim3(a.B), dim3(NMS_NT), lds, s, a, cp2);
     return hipGetLastError();
 }
 
