@@ -1143,9 +1143,11 @@ static hipError_t launch_halo2(const ConvArgs& a, hipStream_t s) {
 // Weights come from the second packed copy with 64-byte K chunks (ConvArgs::wgt32).
 // WN = 1: the 64-channel variant (BN = 64): eight waves of 64 px x 64 ch (two image rows each), one DMA piece of weights
 // per wave and stage, 32 MFMAs per wave between barriers.
-template <bool TAIL, int WN>
+// DUAL = true: maps at most 16 pixels wide (the stride-32 level of a 512-px tile): the 32 patch columns are the 16 columns of
+// TWO consecutive images, each with its own left/right halo column (patch rows of 36 instead of 34 pixels).
+template <bool TAIL, int WN, bool DUAL = false>
 __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
-    constexpr int TH = 16, TW = 32, NW = 8, BN = 64 * WN, PWID = TW + 2;
+    constexpr int TH = 16, TW = 32, NW = 8, BN = 64 * WN, PWID = DUAL ? 36 : TW + 2, HALF = DUAL ? 18 : 16;
     constexpr int RPW = TH / (NW / WN), MIW = 2 * RPW, WPS = WN;          // image rows / pixel fragments per wave; weight pieces per wave and stage
     constexpr int PR = (TH + 2) * PWID, NPC = (PR + 15) / 16, PROUNDS = (NPC + NW - 1) / NW;
     constexpr int P_BYTES = PROUNDS * NW * 1024, SLAB = BN * 64, W_BYTES = 2 * SLAB, RING = 3;
@@ -1157,7 +1159,7 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
     const int H = a.Hi, W = a.Wi;
-    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int tiles_x = DUAL ? 1 : (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     const int cpad = pad128(a.Cout);                      // packed weight rows (zero rows past Cout)
     const int ntn = (pad64(a.Cout) + BN - 1) / BN;
     const int id = xcd_remap(blockIdx.x, gridDim.x);
@@ -1176,10 +1178,12 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
     for (int j = 0; j < PROUNDS; ++j) {
         const int r = (j * NW + wave) * 16 + (lane >> 2);
         const int ry = r / PWID, rx = r - ry * PWID;
-        const int y = y0 + ry - 1, x = x0 + rx - 1;
+        const int half = DUAL ? rx / 18 : 0;                 // DUAL: which of the block's two images this patch column belongs to
+        const int bb = DUAL ? 2 * b + half : b;
+        const int y = y0 + ry - 1, x = DUAL ? rx - half * 18 - 1 : x0 + rx - 1;
         const int q = (lane & 3) ^ (((r >> 2) & 1) << 1);
-        const bool ok = r < PR && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-        poff[j] = ok ? (unsigned)(((b * H + y) * W + x) * a.in0_ct + a.in0_coff + q * 8) * 2u : CY_OOB;
+        const bool ok = r < PR && bb < a.B && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+        poff[j] = ok ? (unsigned)(((bb * H + y) * W + x) * a.in0_ct + a.in0_coff + q * 8) * 2u : CY_OOB;
     }
     unsigned woff;
     {   // WN = 2: every wave moves rows wave*16.. of BOTH taps of a stage; WN = 1: wave -> (tap wave>>2, rows (wave&3)*16..)
@@ -1189,18 +1193,18 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
     auto dma_patch = [&](int buf, int slab) {               // slab: 32-channel slab index
 #pragma unroll
         for (int j = 0; j < PROUNDS; ++j)                    // uniform part in soffset: not range-checked, so the OOB sentinel of
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_void*)(Pbuf + buf * P_BYTES + (j * NW + wave) * 1024), 16, poff[j], slab * 64, 0, 0);   // a lane survives it
+            dma_piece(rs0, (lds_ptr_t*)(Pbuf + buf * P_BYTES + (j * NW + wave) * 1024), poff[j], slab * 64);   // a lane survives it
     };
     auto dma_stage = [&](int ring, int slab0, int u0) {     // taps u0, u0+1 of the pair starting at slab slab0 (u in 0..17)
         if constexpr (WN == 2) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int u = u0 + t, sl = slab0 + u / 9, tap = u % 9;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)(Wbuf + ring * W_BYTES + t * SLAB + wave * 1024), 16, woff, (sl * 9 + tap) * cpad * 64, 0, 0);
+                dma_piece(rsw, (lds_ptr_t*)(Wbuf + ring * W_BYTES + t * SLAB + wave * 1024), woff, (sl * 9 + tap) * cpad * 64);
             }
         } else {
             const int t = wave >> 2, u = u0 + t, sl = slab0 + u / 9, tap = u % 9;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)(Wbuf + ring * W_BYTES + t * SLAB + (wave & 3) * 1024), 16, woff, (sl * 9 + tap) * cpad * 64, 0, 0);
+            dma_piece(rsw, (lds_ptr_t*)(Wbuf + ring * W_BYTES + t * SLAB + (wave & 3) * 1024), woff, (sl * 9 + tap) * cpad * 64);
         }
     };
     f32x4 acc[4][MIW];
@@ -1226,7 +1230,7 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const int mi = half * 4 + m;
-            const int base = ((mi >> 1) + kh) * PWID + (mi & 1) * 16 + kw;
+            const int base = ((mi >> 1) + kh) * PWID + (mi & 1) * HALF + kw;
             dst[m] = *reinterpret_cast<const f16x8*>(smem + pb[base & 7] + (pbuf_off + base * 64));
         }
     };
@@ -1306,9 +1310,10 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
     for (int j = 0; j < 16; ++j) bv[j] = a.bias[cbase + j];
 #pragma unroll
     for (int mi = 0; mi < MIW; ++mi) {
-        const int y = y0 + wm * RPW + (mi >> 1), x = x0 + (mi & 1) * 16 + fr;
-        if (y >= H || x >= W) continue;
-        const long pix = ((long)b * H + y) * W + x;
+        const int y = y0 + wm * RPW + (mi >> 1), x = DUAL ? fr : x0 + (mi & 1) * 16 + fr;
+        const int bb = DUAL ? 2 * b + (mi & 1) : b;
+        if (y >= H || x >= W || bb >= a.B) continue;
+        const long pix = ((long)bb * H + y) * W + x;
         float v[16];
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
@@ -1344,20 +1349,21 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
     }
 }
 
-template <int WN>
+template <int WN, bool DUAL = false>
 static hipError_t launch_wide(const ConvArgs& a, hipStream_t s) {
-    constexpr int PR = 18 * 34, NPC = (PR + 15) / 16, PROUNDS = (NPC + 7) / 8, BN = 64 * WN;
+    constexpr int PR = 18 * (DUAL ? 36 : 34), NPC = (PR + 15) / 16, PROUNDS = (NPC + 7) / 8, BN = 64 * WN;
     const size_t lds = 2 * PROUNDS * 8 * 1024 + 3 * 2 * BN * 64;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wide_kernel<false, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wide_kernel<true, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wide_kernel<false, WN, DUAL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wide_kernel<true, WN, DUAL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    const int blocks = a.B * ((a.Hi + 15) / 16) * ((a.Wi + 31) / 32) * ((pad64(a.Cout) + BN - 1) / BN);
+    const int bx = DUAL ? (a.B + 1) / 2 : a.B * ((a.Wi + 31) / 32);
+    const int blocks = bx * ((a.Hi + 15) / 16) * ((pad64(a.Cout) + BN - 1) / BN);
     static const int tail = getenv("CY_WIDE_TAIL") ? atoi(getenv("CY_WIDE_TAIL")) : 1;
-    if (tail) hipLaunchKernelGGL((conv3x3_wide_kernel<true, WN>), dim3(blocks), dim3(512), lds, s, a);
-    else hipLaunchKernelGGL((conv3x3_wide_kernel<false, WN>), dim3(blocks), dim3(512), lds, s, a);
+    if (tail) hipLaunchKernelGGL((conv3x3_wide_kernel<true, WN, DUAL>), dim3(blocks), dim3(512), lds, s, a);
+    else hipLaunchKernelGGL((conv3x3_wide_kernel<false, WN, DUAL>), dim3(blocks), dim3(512), lds, s, a);
     return hipGetLastError();
 }
 
@@ -1625,7 +1631,7 @@ static const char* const kVariantNames[CONV_NUM_VARIANTS] = {
     "conv3x3_c64_kernel<64|32> 3x3 s1 persistent, Cin 64 or 32", "conv_igemm_kernel<4,2,4,3> generic 256x128, 3-slab ring",
     "conv3x3_wide_kernel 3x3 s1 16x32px x128ch, K slabs of 32",
     "conv1x1_direct_kernel<4,2> 1x1 256px x256ch, pixels to regs", "conv1x1_direct_kernel<2,2> 1x1 256px x128ch, pixels to regs",
-    "conv3x3_wide_kernel<WN=1> 3x3 s1 16x32px x64ch"};
+    "conv3x3_wide_kernel<WN=1> 3x3 s1 16x32px x64ch", "conv3x3_wide_kernel<dual> 3x3 s1 2 images x 16x16px x128ch"};
 const char* conv_variant_name(int v) { return v >= 0 && v < CONV_NUM_VARIANTS ? kVariantNames[v] : "?"; }
 
 static bool s2_direct() { static const int v = getenv("CY_S2_DIRECT") ? atoi(getenv("CY_S2_DIRECT")) : 1; return v != 0; }
@@ -1653,6 +1659,12 @@ int conv_variant(Precision p, const ConvArgs& a) {
         static const int wide = getenv("CY_WIDE") ? atoi(getenv("CY_WIDE")) : 1;
         const int wpad = (a.Wi + 31) / 32 * 32;
         if (wide && a.wgt32 && (wpad - a.Wi) * 8 <= a.Wi) return CONV_WIDE_128;     // <= 12.5 % of the patch columns idle
+        const int dual = getenv("CY_WIDE_DUAL") ? atoi(getenv("CY_WIDE_DUAL")) : 1;      // read per call: 2 forces it (tests)
+        // two 16-px-wide images side by side: +8 % over the two-tap halo kernel once it still fills the chip (half as many
+        // workgroups), slower below that
+        if (wide && dual && a.wgt32 && a.Wi <= 16 && a.Wi >= 14 &&
+            (long)((a.B + 1) / 2) * ((a.Hi + 15) / 16) * ((pad64(a.Cout) + 127) / 128) >= (dual > 1 ? 1 : 384))
+            return CONV_WIDE_DUAL;
         return CONV_HALO8_128;
     }
     if (narrow) return CONV_GENERIC_64;
@@ -1688,6 +1700,7 @@ hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s) {
         case CONV_GENERIC_BIG: return launch_t<f16, 4, 2, 4, 3>(a, s);
         case CONV_WIDE_128: return launch_wide<2>(a, s);
         case CONV_WIDE_64: return launch_wide<1>(a, s);
+        case CONV_WIDE_DUAL: return launch_wide<2, true>(a, s);
         case CONV_DIRECT_256: return a.k == 3 ? launch_direct<4, 2, 3, true>(a, s) : launch_direct<4, 2, 3, false>(a, s);
         case CONV_DIRECT_128:     // strided 3x3 (model.1): 64 px per wave, so every weight fragment feeds four MFMAs (-8 % vs 32 px)
             return a.k == 3 ? launch_direct<2, 4, 2, true>(a, s) : launch_direct<2, 2, 4, false>(a, s);

@@ -36,7 +36,9 @@ CASES = [  # B, H, W, Cin, Cout, k, s, act, residual
     (3, 30, 60, 64, 256, 3, 1, True, False),      # wide kernel: ragged columns (60 of 64) and rows, one slab pair
     (6, 64, 64, 32, 32, 3, 1, True, True),        # persistent kernel, 32-channel variant (64-byte LDS rows), residual
     (3, 40, 50, 32, 64, 3, 1, True, False),       # 32 -> 64 channels, ragged patches
-    (40, 32, 64, 128, 64, 3, 1, True, False),     # 64-channel variant of the wide kernel (box head), two slab pairs
+    (40, 32, 64, 128, 64, 3, 1, True, False),     # 64-channel variant of the wide kernel
+    (9, 16, 16, 256, 256, 3, 1, True, True),      # dual-image variant of the wide kernel (16-px maps), odd batch, residual
+    (4, 14, 15, 128, 192, 3, 1, True, False),     # dual-image variant, ragged 14x15 maps, Cout 192 (box head), two slab pairs
     (16, 128, 128, 128, 128, 3, 2, True, False),  # pixels-direct kernel, 3x3 stride 2 (taps as uniform address shifts), 128-ch tile
     (5, 130, 126, 128, 320, 3, 2, True, False),   # pixels-direct 3x3 s2: odd rows/cols at the border, ragged 256-ch tiles, 18 K chunks
 ]
@@ -44,7 +46,8 @@ CASES = [  # B, H, W, Cin, Cout, k, s, act, residual
 
 @pytest.mark.parametrize("prec", ["fp32", "fp16"])
 @pytest.mark.parametrize("case", CASES)
-def test_conv_bn_silu(prec, case):
+def test_conv_bn_silu(prec, case, monkeypatch):
+    monkeypatch.setenv("CY_WIDE_DUAL", "2")       # the dual-image kernel normally waits for benchmark-sized batches: force it here
     B, H, W, Cin, Cout, k, s, act, use_res = case
     det = detector(prec)
     g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
