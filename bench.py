@@ -235,7 +235,8 @@ def main():
             out["forward_kernels"] = [{"kernel": p["kernel"], "ms_total": p["ms"], "launches": p["launches"],
                                        "TFLOP/s": (p["flops"] / (p["ms"] * 1e-3) / 1e12) if p["ms"] > 0 else 0.0,
                                        "share_of_forward": p["ms"] / tot_ms if tot_ms else 0.0} for p in prof]
-            out["forward_share_of_step"] = tot_ms / (1000.0 * dt) if dt > 0 else None
+            out["profiled_forward_share_of_step"] = tot_ms / (1000.0 * dt) if dt > 0 else None   # only every 2nd batch is timed
+            out["profile_stride_batches"] = 2
         if world == 1 and not args.no_cpu_baseline:
             scale, names, wd, _ = W.read_cyw(model._wpath)
             out["cpu_baseline"] = cpu_baseline(mosaic_host, grid, (scale, names, wd))

@@ -1305,6 +1305,23 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
     }
 
     const int cbase = n0 + wn * 64 + fq * 16;
+    // Residual (bottleneck shortcut): all of this wave's 2*MIW vectors are requested up front (the fragment registers are
+    // free now), so the epilogue pays ONE memory round trip instead of one per pixel fragment (1 workgroup per CU: nothing
+    // else hides it).  Out-of-range pixels read the zero of the buffer range check.
+    const bool res_vec = a.res != nullptr && cbase + 16 <= a.Cout;
+    f16x8 rv[MIW][2];
+    if (res_vec) {
+        const auto rsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.res), 0, (unsigned)((long)a.B * H * W * a.res_ct * 2), 0x00020000);
+#pragma unroll
+        for (int mi = 0; mi < MIW; ++mi) {
+            const int y = y0 + wm * RPW + (mi >> 1), x = DUAL ? fr : x0 + (mi & 1) * 16 + fr;
+            const int bb = DUAL ? 2 * b + (mi & 1) : b;
+            const bool ok = y < H && x < W && bb < a.B;
+            const unsigned ro = ok ? (unsigned)((((bb * H + y) * W + x) * a.res_ct + a.res_coff + cbase) * 2) : CY_OOB;
+            rv[mi][0] = __builtin_bit_cast(f16x8, load_b128(rsr, ro, 0));
+            rv[mi][1] = __builtin_bit_cast(f16x8, load_b128(rsr, ro, 16));
+        }
+    }
     float bv[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) bv[j] = a.bias[cbase + j];
@@ -1325,11 +1342,9 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
             }
         if (cbase + 16 <= a.Cout) {
             f16* dst = reinterpret_cast<f16*>(a.out) + pix * a.out_ct + a.out_coff + cbase;
-            if (a.res) {
-                const f16* rp = reinterpret_cast<const f16*>(a.res) + pix * a.res_ct + a.res_coff + cbase;
-                const f16x8 r0v = *reinterpret_cast<const f16x8*>(rp), r1v = *reinterpret_cast<const f16x8*>(rp + 8);
+            if (res_vec) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { v[j] += (float)r0v[j]; v[8 + j] += (float)r1v[j]; }
+                for (int j = 0; j < 8; ++j) { v[j] += (float)rv[mi][0][j]; v[8 + j] += (float)rv[mi][1][j]; }
             }
             f16x8 o0, o1;
 #pragma unroll
@@ -1663,7 +1678,7 @@ int conv_variant(Precision p, const ConvArgs& a) {
         // two 16-px-wide images side by side: +8 % over the two-tap halo kernel once it still fills the chip (half as many
         // workgroups), slower below that
         if (wide && dual && a.wgt32 && a.Wi <= 16 && a.Wi >= 14 &&
-            (long)((a.B + 1) / 2) * ((a.Hi + 15) / 16) * ((pad64(a.Cout) + 127) / 128) >= (dual > 1 ? 1 : 384))
+            (long)((a.B + 1) / 2) * ((a.Hi + 15) / 16) * ((pad64(a.Cout) + 127) / 128) >= (dual > 1 ? 1 : 256))
             return CONV_WIDE_DUAL;
         return CONV_HALO8_128;
     }
