@@ -1902,6 +1902,200 @@ void pack_stem_weights(const float* W, int cout, void* dst) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ stem + first down conv
+// model.0 (3x3 s2, 3 -> 64) and model.1 (3x3 s2, 64 -> 128) fused.  As separate layers they are the two slowest launches
+// of the forward pass and both HBM-bound: the 64-channel half-resolution map is 8.4 MB per 512x512 tile, written once and
+// read back ~1.6 times (the nine taps of a stride-2 conv come back long after each other: the L2 does not hold them).
+// Here a workgroup owns 8 x 32 output pixels of model.1 x all 128 channels:
+//   phase 1: the 17 x 65 stem pixels under them are computed on the matrix cores (K = 9 taps x 4 NHWC channels = 36,
+//            padded to 64: a lane's k-chunk is two whole input pixels = two 8-byte loads) and written, bias + SiLU applied,
+//            to LDS as fp16 [row][64 ch] (138 KiB).  Stem pixels outside the map are model.1's zero padding: zeros.
+//            Rows are split by column parity (even columns first), so the 16 pixels of a stride-2 fragment are 16
+//            CONSECUTIVE LDS rows and the usual chunk ^ (row & 7) swizzle keeps ds_read_b128 conflict-free.
+//   phase 2: 9 taps x 2 K-halves; a wave owns 64 px x 64 ch, reads its pixel fragments from LDS and its weight fragments
+//            straight from global memory (the 147 KB panel is L2-resident; no LDS left for it), one step ahead.
+// HBM traffic: input (0.5 MB/tile x 1.08 halo) + output (4.2 MB/tile) instead of + 8.4 MB written + >= 8.4 MB read.
+constexpr int SD_TH = 8, SD_TW = 32, SD_PH = 2 * SD_TH + 1, SD_PW = 2 * SD_TW + 1, SD_EVEN = SD_TW + 1;
+constexpr int SD_ROWS = SD_PH * SD_PW, SD_FRAGS = (SD_ROWS + 15) / 16, SD_LDS = SD_FRAGS * 16 * 128;
+
+__device__ __forceinline__ u32x2 load_b64(__amdgpu_buffer_rsrc_t rs, unsigned voff) {
+    return __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, 0);
+}
+
+__global__ __launch_bounds__(512) void stem_down_kernel(const StemDownArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1, wm = wave >> 1;
+    const int tiles_x = (a.Wo + SD_TW - 1) / SD_TW, tiles_y = (a.Ho + SD_TH - 1) / SD_TH;
+    int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int tx = id % tiles_x; id /= tiles_x;
+    const int ty = id % tiles_y;
+    const int b = id / tiles_y;
+    const int oy0 = ty * SD_TH, ox0 = tx * SD_TW;
+    const int sy0 = 2 * oy0 - 1, sx0 = 2 * ox0 - 1;          // stem-map coordinates of LDS pixel (0, 0)
+    const auto rsi = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, a.in_bytes, 0x00020000);
+    const auto rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wgt32), 0, a.wgt32_bytes, 0x00020000);
+
+    // weight fragments of step (tap, h): rows wn*64 + ni*16 + fr of chunk h, bytes fq*16.. ; cpad = 128 rows of 64 B
+    f16x8 wa[4][4];                                           // ring: fragments are requested three steps (~0.7 us of MFMAs) ahead
+    const unsigned wl = (unsigned)((wn * 64 + fr) * 64 + fq * 16);
+    auto load_wa = [&](f16x8* dst, int step) {
+        const int h = step & 1, tap = step >> 1;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) dst[ni] = __builtin_bit_cast(f16x8, load_b128(rsw, wl + ni * 1024, (h * 9 + tap) * 8192));
+    };
+    load_wa(wa[0], 0);                                       // in flight during phase 1
+    load_wa(wa[1], 1);
+    load_wa(wa[2], 2);
+
+    {   // ---- phase 1: stem pixels -> LDS
+        const f16* wp = reinterpret_cast<const f16*>(a.wpk2);
+        f16x8 sw0[4], sw1[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            sw0[ni] = *reinterpret_cast<const f16x8*>(wp + (ni * 16 + fr) * 64 + fq * 8);
+            sw1[ni] = *reinterpret_cast<const f16x8*>(wp + (ni * 16 + fr) * 64 + 32 + fq * 8);
+        }
+        float bv[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) bv[j] = a.bias0[fq * 16 + j];
+        const int t0 = 2 * fq, t1 = 2 * fq + 1;              // the two taps of this lane's k-chunk; tap 8 rides in the second MFMA (fq = 0)
+        const int dh0 = t0 / 3 - 1, dw0 = t0 % 3 - 1, dh1 = t1 / 3 - 1, dw1 = t1 % 3 - 1;
+        constexpr int NG = (SD_FRAGS + 7) / 8;
+        u32x2 q0[NG], q1[NG], q2[NG];
+        unsigned inmask = 0;
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            const int g = gi * 8 + wave, p = g * 16 + fr;
+            const int sy = p / SD_PW, q = p - sy * SD_PW;
+            const int sx = q < SD_EVEN ? 2 * q : 2 * (q - SD_EVEN) + 1;
+            const int Y = sy0 + sy, X = sx0 + sx;
+            const bool inmap = p < SD_ROWS && (unsigned)Y < (unsigned)a.H1 && (unsigned)X < (unsigned)a.W1;
+            inmask |= inmap ? (1u << gi) : 0u;
+            auto off = [&](int dh, int dw) -> unsigned {
+                const int hi = 2 * Y + dh, wi = 2 * X + dw;
+                const bool ok = inmap && (unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi;
+                return ok ? (unsigned)(((b * a.Hi + hi) * a.Wi + wi) * 8) : CY_OOB;
+            };
+            q0[gi] = load_b64(rsi, off(dh0, dw0));
+            q1[gi] = load_b64(rsi, off(dh1, dw1));
+            const unsigned o8 = off(1, 1);
+            q2[gi] = load_b64(rsi, fq == 0 ? o8 : CY_OOB);
+        }
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            const int g = gi * 8 + wave;
+            if (g >= SD_FRAGS) break;                         // wave-uniform
+            const int p = g * 16 + fr;
+            const bool inmap = (inmask >> gi) & 1u;
+            // the fourth NHWC channel is padding: its weights are zero, and masking it keeps a stray NaN out of the sum
+            const u32x4 u0 = {q0[gi].x, q0[gi].y & 0xFFFFu, q1[gi].x, q1[gi].y & 0xFFFFu};
+            const u32x4 u1 = {q2[gi].x, q2[gi].y & 0xFFFFu, 0u, 0u};
+            const f16x8 x0 = __builtin_bit_cast(f16x8, u0), x1 = __builtin_bit_cast(f16x8, u1);
+            f32x4 acc[4];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sw0[ni], x0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sw1[ni], x1, acc[ni], 0, 0, 0);
+            }
+            f16x8 o0, o1;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = silu_fast(acc[ni][j] + bv[ni * 4 + j]);
+                    if (ni < 2) o0[ni * 4 + j] = (f16)v; else o1[(ni - 2) * 4 + j] = (f16)v;
+                }
+            const unsigned keep = inmap ? 0xFFFFFFFFu : 0u;   // a select on the packed result: a `?:` around silu becomes 16 branches
+            const u32x4 k4 = {keep, keep, keep, keep};
+            char* row = smem + p * 128;
+            *reinterpret_cast<u32x4*>(row + (((2 * fq) ^ (p & 7)) << 4)) = __builtin_bit_cast(u32x4, o0) & k4;
+            *reinterpret_cast<u32x4*>(row + (((2 * fq + 1) ^ (p & 7)) << 4)) = __builtin_bit_cast(u32x4, o1) & k4;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: 3x3 stride 2 over the LDS patch
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[ni][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int pl = wm * 4 * SD_PW + fr;                      // LDS row of (first output row of this wave, tap (0,0), column fr)
+#pragma unroll
+    for (int step = 0; step < 18; ++step) {
+        const int tap = step >> 1, h = step & 1, kh = tap / 3, kw = tap % 3;
+        if (step + 3 < 18) load_wa(wa[(step + 3) & 3], step + 3);
+        __builtin_amdgcn_sched_barrier(0);                   // (left alone the compiler sinks each load to just before its MFMAs)
+        f16x8 xb[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int cm = (2 * (m >> 1) + kh) * SD_PW + (m & 1) * 16 + (kw == 1 ? SD_EVEN : (kw == 2 ? 1 : 0));
+            const int p = pl + cm;
+            xb[m] = *reinterpret_cast<const f16x8*>(smem + p * 128 + (((h * 4 + fq) ^ (p & 7)) << 4));
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                acc[ni][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[step & 3][ni], xb[m], acc[ni][m], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    const int cbase = wn * 64 + fq * 16;
+    float bv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) bv[j] = a.bias1[cbase + j];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int oy = oy0 + wm * 2 + (m >> 1), ox = ox0 + (m & 1) * 16 + fr;
+        if (oy >= a.Ho || ox >= a.Wo) continue;
+        const long pix = ((long)b * a.Ho + oy) * a.Wo + ox;
+        f16x8 o0, o1;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = silu_fast(acc[ni][m][j] + bv[ni * 4 + j]);
+                if (ni < 2) o0[ni * 4 + j] = (f16)v; else o1[(ni - 2) * 4 + j] = (f16)v;
+            }
+        f16* dst = reinterpret_cast<f16*>(a.out) + pix * a.out_ct + a.out_coff + cbase;
+        *reinterpret_cast<f16x8*>(dst) = o0;
+        *reinterpret_cast<f16x8*>(dst + 8) = o1;
+    }
+}
+
+long stem_down_blocks(const StemDownArgs& a) {
+    return (long)a.B * ((a.Ho + SD_TH - 1) / SD_TH) * ((a.Wo + SD_TW - 1) / SD_TW);
+}
+
+hipError_t launch_stem_down(const StemDownArgs& a, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(stem_down_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SD_LDS);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(stem_down_kernel, dim3((unsigned)stem_down_blocks(a)), dim3(512), SD_LDS, s, a);
+    return hipGetLastError();
+}
+
+// stem panel of stem_down_kernel: [64 rows, permuted like pack_weights][64] fp16; k = tap*4 + c for taps 0..7, 32 + c for
+// tap 8 (c = NHWC4 channel, the fourth is zero)
+void pack_stem_weights2(const float* W, int cout, void* dst) {
+    f16* o = reinterpret_cast<f16*>(dst);
+    for (int row = 0; row < 64; ++row) {
+        const int ni = (row >> 4) & 3, rr = row & 15;
+        const int n = (rr >> 2) * 16 + ni * 4 + (rr & 3);
+        for (int k = 0; k < 64; ++k) {
+            const int tap = k < 32 ? k / 4 : 8, c = k < 32 ? k % 4 : k - 32;
+            float v = 0.0f;
+            if (n < cout && c < 3 && k < 36) v = W[((size_t)n * 3 + c) * 9 + tap];
+            o[row * 64 + k] = (f16)v;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ SPPF pool
 // MaxPool2d(kernel 5, stride 1, padding 2) with implicit -inf padding, slice -> slice of one NHWC buffer.
 template <typename T>

@@ -34,6 +34,16 @@ struct StemArgs {
     int B, Hi, Wi, Ho, Wo, Cout, out_ct, out_coff;
 };
 
+// model.0 + model.1 of the YOLOv8/YOLO11 graphs in one kernel (fp16 context): the 64-channel half-resolution map (8 MB
+// per 512x512 tile) never goes to HBM
+struct StemDownArgs {
+    const void* in; uint32_t in_bytes; int B, Hi, Wi;                  // NHWC4 fp16 network input
+    const void* wpk2; const float* bias0;                               // stem panel [64][64] fp16 (pack_stem_weights2), bias
+    const void* wgt32; uint32_t wgt32_bytes; const float* bias1;        // 3x3 s2 64->128 weights, 64-byte K chunks (pack_weights(..., 64))
+    void* out; int out_ct, out_coff;
+    int H1, W1, Ho, Wo;                                                 // stem map, output map
+};
+
 struct PoolArgs {   // MaxPool2d(5,1,2) on a channel slice of an NHWC buffer, -inf padding
     const void* src; void* dst; int ct, src_coff, dst_coff, C, B, H, W;
 };
@@ -56,6 +66,9 @@ int conv_variant(Precision p, const ConvArgs& a);          // which kernel launc
 const char* conv_variant_name(int v);
 void debug_read_stamps(unsigned long long* out8, bool reset);   // developer diagnostics (CY_DBG=64)
 hipError_t launch_stem(Precision p, const StemArgs& a, hipStream_t s);
+hipError_t launch_stem_down(const StemDownArgs& a, hipStream_t s);
+long stem_down_blocks(const StemDownArgs& a);
+void pack_stem_weights2(const float* W, int cout, void* dst);     // 64*64 fp16, k = tap*4 + c (taps 0..7), 32 + c (tap 8)
 hipError_t launch_pool5(Precision p, const PoolArgs& a, hipStream_t s);
 
 // Host-side weight packing into the layout launch_conv expects.

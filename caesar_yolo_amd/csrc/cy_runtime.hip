@@ -45,6 +45,7 @@ struct cy_ctx {
     unsigned long batches = 0;                          // cy_detect_tiles calls since load / flush
     // optional per-launch timing of the forward ops (hipEvents on the caller's stream)
     bool profiling = false;
+    bool stem_fused_last = false;                        // the last forward ran model.0 + model.1 as one kernel (no model.0 tensor)
     int prof_stride = 1; unsigned long fwd_calls = 0;   // profiling on: every prof_stride-th cy_forward call is timed
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
     struct ProfRec { size_t e0, e1; int kind; double flops; int conv; };
@@ -202,8 +203,9 @@ int upload_weights(cy_ctx* c, const void* buf, size_t nbytes) {
             HIPCHK(c, hipMalloc(&dc.stem_w, 4 * sw.size()));
             HIPCHK(c, hipMemcpy(dc.stem_w, sw.data(), 4 * sw.size(), hipMemcpyHostToDevice));
             if (c->prec == PREC_F16 && co == 64) {
-                std::vector<char> pk(64 * 32 * 2);
+                std::vector<char> pk(64 * 32 * 2 + 64 * 64 * 2);          // panel of stem_mfma_kernel, then the one of stem_down_kernel
                 pack_stem_weights(W, (int)co, pk.data());
+                pack_stem_weights2(W, (int)co, pk.data() + 64 * 32 * 2);
                 HIPCHK(c, hipMalloc(&dc.w, pk.size()));
                 HIPCHK(c, hipMemcpy(dc.w, pk.data(), pk.size(), hipMemcpyHostToDevice));
             }
@@ -215,7 +217,8 @@ int upload_weights(cy_ctx* c, const void* buf, size_t nbytes) {
         pack_weights(c->prec, W, co, ci, k, packed.data());
         HIPCHK(c, hipMalloc(&dc.w, dc.wbytes));
         HIPCHK(c, hipMemcpy(dc.w, packed.data(), dc.wbytes, hipMemcpyHostToDevice));
-        if (c->prec == PREC_F16 && k == 3 && s == 1 && ((ci % 64 == 0 && co >= 33) || (ci == 32 && co <= 64))) {   // second copy (64-byte K chunks) for conv3x3_wide_kernel / conv3x3_c64_kernel<32>
+        // (also the 3x3 s2 64->128 layer behind the stem: stem_down_kernel reads its weight fragments from this copy)
+        if (c->prec == PREC_F16 && k == 3 && ((s == 1 && ((ci % 64 == 0 && co >= 33) || (ci == 32 && co <= 64))) || (s == 2 && ci == 64 && co == 128))) {   // second copy (64-byte K chunks) for conv3x3_wide_kernel / conv3x3_c64_kernel<32>
             dc.w32bytes = packed_weight_bytes(c->prec, co, ci, k, 64);
             packed.resize(dc.w32bytes);
             pack_weights(c->prec, W, co, ci, k, packed.data(), 64);
@@ -421,13 +424,46 @@ int cy_forward(cy_ctx* c, const void* d_netin, int B, int H, int W, float* d_pre
     crosses[0] = 1;
     const int sub = (sub_env > 0 && sub_env < B && n_head > 0) ? sub_env : B;
 
-    auto run_op = [&](const Op& o, int b0, int Bn) -> int {
+    // model.0 + model.1 in one kernel (fp16 context) when the stem's only reader is a 3x3 s2 64->128 SiLU conv and the launch
+    // fills the chip.  CY_STEM_FUSE: 0 = off, 2 = regardless of size (parity tests); read per call.
+    const int fuse_env = getenv("CY_STEM_FUSE") ? atoi(getenv("CY_STEM_FUSE")) : 1;
+    auto stem_fusable = [&](const Op& o, const Op& n) -> bool {
+        if (c->prec != PREC_F16 || !fuse_env || o.kind != OPK_STEM || n.kind != OPK_CONV || n.conv < 0 || n.out < 0) return false;
+        const ConvDesc& d0 = p.convs[o.conv]; const ConvDesc& d = p.convs[n.conv];
+        if (d0.cout != 64 || !c->dconv[o.conv].w || !c->dconv[n.conv].w32) return false;
+        if (d.k != 3 || d.s != 2 || d.cin != 64 || d.cout != 128 || !d.act) return false;
+        if (n.in0 != o.out || n.in0_coff != o.out_coff || n.c0 != 64 || n.in1 >= 0 || n.res >= 0 || n.up0) return false;
+        if (p.tensors[o.out].C != 64) return false;
+        int readers = 0;
+        for (const Op& q : p.ops) readers += (q.in0 == o.out) + (q.in1 == o.out) + (q.res == o.out);
+        return readers == 1;
+    };
+    c->stem_fused_last = false;
+
+    auto run_op = [&](const Op& o, const Op* next, int b0, int Bn, bool* fused) -> int {
         auto tp = [&](int t) -> char* {                    // tensor base for images [b0, b0+Bn)
             char* base = tptr(t);
             if (b0 && crosses[t]) base += (size_t)b0 * (H >> p.tensors[t].level) * (W >> p.tensors[t].level) * p.tensors[t].C * es;
             return base;
         };
         cur_conv = o.conv;
+        if (o.kind == OPK_STEM && next && stem_fusable(o, *next)) {
+            const Op& n = *next;
+            const Tensor& ti = p.tensors[o.in0]; const Tensor& t1 = p.tensors[o.out]; const Tensor& to = p.tensors[n.out];
+            StemDownArgs a{};
+            a.B = Bn; a.Hi = H >> ti.level; a.Wi = W >> ti.level; a.H1 = H >> t1.level; a.W1 = W >> t1.level;
+            a.Ho = a.H1 / 2; a.Wo = a.W1 / 2;
+            a.in = tp(o.in0); a.in_bytes = (uint32_t)((size_t)Bn * a.Hi * a.Wi * ti.C * es);
+            a.wpk2 = reinterpret_cast<const char*>(c->dconv[o.conv].w) + 64 * 32 * 2; a.bias0 = c->dconv[o.conv].bias;
+            a.wgt32 = c->dconv[n.conv].w32; a.wgt32_bytes = (uint32_t)c->dconv[n.conv].w32bytes; a.bias1 = c->dconv[n.conv].bias;
+            a.out = tp(n.out); a.out_ct = to.C; a.out_coff = n.out_coff;
+            if (ti.C == 4 && (fuse_env > 1 || stem_down_blocks(a) >= 256)) {
+                HIPCHK(c, launch_stem_down(a, s));
+                prof_done(CONV_NUM_VARIANTS, 2.0 * Bn * a.H1 * a.W1 * 64 * 27.0 + 2.0 * Bn * a.Ho * a.Wo * 128.0 * 64 * 9);
+                *fused = true; c->stem_fused_last = true;
+                return CY_OK;
+            }
+        }
         if (o.kind == OPK_STEM) {
             const Tensor& ti = p.tensors[o.in0]; const Tensor& to = p.tensors[o.out];
             StemArgs a{};
@@ -499,12 +535,20 @@ int cy_forward(cy_ctx* c, const void* d_netin, int B, int H, int W, float* d_pre
         }
         return CY_OK;
     };
+    auto run_range = [&](size_t lo, size_t hi, int b0, int Bn) -> int {
+        for (size_t i = lo; i < hi; ++i) {
+            bool fused = false;
+            const int r = run_op(p.ops[i], i + 1 < hi ? &p.ops[i + 1] : nullptr, b0, Bn, &fused);
+            if (r) return r;
+            if (fused) ++i;                                  // the next op ran inside this one's kernel
+        }
+        return CY_OK;
+    };
     for (int b0 = 0; b0 < B; b0 += sub) {
         const int Bn = B - b0 < sub ? B - b0 : sub;
-        for (size_t i = 0; i < n_head; ++i) { rc = run_op(p.ops[i], b0, Bn); if (rc) return rc; }
+        rc = run_range(0, n_head, b0, Bn); if (rc) return rc;
     }
-    for (size_t i = n_head; i < p.ops.size(); ++i) { rc = run_op(p.ops[i], 0, B); if (rc) return rc; }
-    return CY_OK;
+    return run_range(n_head, p.ops.size(), 0, B);
 }
 
 int cy_profile_enable(cy_ctx* c, int on) {
@@ -557,6 +601,8 @@ int cy_debug_read_conv(cy_ctx* c, const char* conv_name, float* h_out, size_t ca
     for (const Op& o : p.ops) {
         if (o.conv < 0 || p.convs[o.conv].name != conv_name) continue;      // pool and attention ops carry no convolution
         if (o.out < 0) return fail(c, CY_ERR_UNSUPPORTED, "head outputs are read from d_pred");
+        if (o.kind == OPK_STEM && c->stem_fused_last)
+            return fail(c, CY_ERR_STATE, "the stem output was not materialised (fused into the next layer's kernel); set CY_STEM_FUSE=0");
         const Tensor& t = p.tensors[o.out];
         const int Ho = c->lastH >> t.level, Wo = c->lastW >> t.level, C = p.convs[o.conv].cout, B = c->lastB;
         const size_t n = (size_t)B * C * Ho * Wo;

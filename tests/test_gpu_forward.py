@@ -40,7 +40,9 @@ TAPS = ["model.0", "model.1", "model.2.cv1", "model.2.m.2.cv1", "model.12.m.0.cv
     ("fp32", 2e-4, 1e-4, {}), ("fp16", 6e-2, 3e-2, {}),
     # the kernels that only take over at benchmark-sized batches, forced on this small one: pixels-direct 1x1 (incl. the
     # upsample+concat inputs of layers 12/15), and with it off, the 256x128 ring kernel
-    ("fp16", 6e-2, 3e-2, {"CY_DIRECT_MIN_BLOCKS": "1"}), ("fp16", 6e-2, 3e-2, {"CY_DIRECT_MIN_BLOCKS": "-1"})])
+    ("fp16", 6e-2, 3e-2, {"CY_DIRECT_MIN_BLOCKS": "1"}), ("fp16", 6e-2, 3e-2, {"CY_DIRECT_MIN_BLOCKS": "-1"}),
+    # model.0 + model.1 as one kernel (default from 256 workgroups on); the model.0 tensor does not exist then
+    ("fp16", 6e-2, 3e-2, {"CY_STEM_FUSE": "2"})])
 def test_forward_matches_oracle(prec, tol_raw, tol_tap, env, monkeypatch):
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -51,6 +53,10 @@ def test_forward_matches_oracle(prec, tol_raw, tol_tap, env, monkeypatch):
     torch.cuda.synchronize()
     for name in TAPS:
         ref = taps[name]
+        if name == "model.0" and env.get("CY_STEM_FUSE") == "2":
+            with pytest.raises(Exception, match="not materialised"):
+                det.read_conv(name, ref.numel())
+            continue
         got = torch.from_numpy(det.read_conv(name, ref.numel()))
         assert tuple(got.shape) == tuple(ref.shape), name
         sc = max(float(ref.abs().max()), 1.0)
@@ -71,6 +77,25 @@ def test_forward_ragged_letterboxed_shape_fp32():
     torch.cuda.synchronize()
     err = float((pred.cpu() - raw).abs().max())
     assert err <= 2e-4 * max(1.0, float(raw.abs().max())), err
+
+
+@pytest.mark.parametrize("fuse", ["0", "2"])
+def test_forward_ragged_letterboxed_shape_fp16(fuse, monkeypatch):
+    """Same non-square grid in the fp16 context, with and without the fused stem kernel (104-px-wide output map: partial
+    32-px tiles, stem pixels outside the map are the next layer's zero padding)."""
+    monkeypatch.setenv("CY_STEM_FUSE", fuse)
+    det = detector("fp16")
+    base = _tile("big512")
+    imgs = [base[:512, :394].copy(), base[:512, 100:494].copy(), base[:512, 118:512].copy()]
+    x, raw, taps = _oracle_forward(imgs, 512)
+    pred = det.forward(netin_from_chw(x, det.dtype))
+    torch.cuda.synchronize()
+    ref = taps["model.1"]
+    got = torch.from_numpy(det.read_conv("model.1", ref.numel()))
+    err = float((got - ref).abs().max())
+    assert err <= 4e-3 * max(1.0, float(ref.abs().max())), "model.1: %.3e" % err
+    err = float((pred.cpu() - raw).abs().max())
+    assert err <= 6e-2 * max(1.0, float(raw.abs().max())), err
 
 
 @pytest.mark.parametrize("scale,nc", [("n", 5), ("s", 3)])
