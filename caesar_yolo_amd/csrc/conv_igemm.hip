@@ -1678,7 +1678,7 @@ int conv_variant(Precision p, const ConvArgs& a) {
         // two 16-px-wide images side by side: +8 % over the two-tap halo kernel once it still fills the chip (half as many
         // workgroups), slower below that
         if (wide && dual && a.wgt32 && a.Wi <= 16 && a.Wi >= 14 &&
-            (long)((a.B + 1) / 2) * ((a.Hi + 15) / 16) * ((pad64(a.Cout) + 127) / 128) >= (dual > 1 ? 1 : 256))
+            (long)((a.B + 1) / 2) * ((a.Hi + 15) / 16) * ((pad64(a.Cout) + 127) / 128) >= (dual > 1 ? 1 : 224))
             return CONV_WIDE_DUAL;
         return CONV_HALO8_128;
     }
@@ -1915,6 +1915,9 @@ void pack_stem_weights(const float* W, int cout, void* dst) {
 //   phase 2: 9 taps x 2 K-halves; a wave owns 64 px x 64 ch, reads its pixel fragments from LDS and its weight fragments
 //            straight from global memory (the 147 KB panel is L2-resident; no LDS left for it), one step ahead.
 // HBM traffic: input (0.5 MB/tile x 1.08 halo) + output (4.2 MB/tile) instead of + 8.4 MB written + >= 8.4 MB read.
+// Measured at batch 256 (CY_SD_DBG phase switches): 1.38 ms against 1.03 + 1.13 ms for the two layers; phase 1 0.70 ms (one
+// exposed gather latency + 144 SiLU per lane per tile), phase 2 0.39 ms, epilogue + stores 0.38 ms.  An 8 x 16-pixel variant
+// with two workgroups per CU (72 KiB, 114 VGPRs) was no faster: its 8-MFMA steps are too short to cover the weight fetch.
 constexpr int SD_TH = 8, SD_TW = 32, SD_PH = 2 * SD_TH + 1, SD_PW = 2 * SD_TW + 1, SD_EVEN = SD_TW + 1;
 constexpr int SD_ROWS = SD_PH * SD_PW, SD_FRAGS = (SD_ROWS + 15) / 16, SD_LDS = SD_FRAGS * 16 * 128;
 
@@ -1938,18 +1941,18 @@ __global__ __launch_bounds__(512) void stem_down_kernel(const StemDownArgs a) {
     const auto rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wgt32), 0, a.wgt32_bytes, 0x00020000);
 
     // weight fragments of step (tap, h): rows wn*64 + ni*16 + fr of chunk h, bytes fq*16.. ; cpad = 128 rows of 64 B
-    f16x8 wa[4][4];                                           // ring: fragments are requested three steps (~0.7 us of MFMAs) ahead
+    constexpr int SD_RING = 4;                                // ring: fragments are requested three steps ahead (a ring of 8 measured
+    f16x8 wa[SD_RING][4];                                     // 6 % slower: its 28 loads per lane up front delay phase 1's gathers)
     const unsigned wl = (unsigned)((wn * 64 + fr) * 64 + fq * 16);
     auto load_wa = [&](f16x8* dst, int step) {
         const int h = step & 1, tap = step >> 1;
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) dst[ni] = __builtin_bit_cast(f16x8, load_b128(rsw, wl + ni * 1024, (h * 9 + tap) * 8192));
     };
-    load_wa(wa[0], 0);                                       // in flight during phase 1
-    load_wa(wa[1], 1);
-    load_wa(wa[2], 2);
+#pragma unroll
+    for (int st = 0; st < SD_RING - 1; ++st) load_wa(wa[st], st);      // in flight during phase 1
 
-    {   // ---- phase 1: stem pixels -> LDS
+    if (!(a.dbg & 1)) {   // ---- phase 1: stem pixels -> LDS
         const f16* wp = reinterpret_cast<const f16*>(a.wpk2);
         f16x8 sw0[4], sw1[4];
 #pragma unroll
@@ -1962,6 +1965,7 @@ __global__ __launch_bounds__(512) void stem_down_kernel(const StemDownArgs a) {
         for (int j = 0; j < 16; ++j) bv[j] = a.bias0[fq * 16 + j];
         const int t0 = 2 * fq, t1 = 2 * fq + 1;              // the two taps of this lane's k-chunk; tap 8 rides in the second MFMA (fq = 0)
         const int dh0 = t0 / 3 - 1, dw0 = t0 % 3 - 1, dh1 = t1 / 3 - 1, dw1 = t1 % 3 - 1;
+        const int d0 = (dh0 * a.Wi + dw0) * 8, d1 = (dh1 * a.Wi + dw1) * 8, d2 = (a.Wi + 1) * 8;
         constexpr int NG = (SD_FRAGS + 7) / 8;
         u32x2 q0[NG], q1[NG], q2[NG];
         unsigned inmask = 0;
@@ -1973,15 +1977,13 @@ __global__ __launch_bounds__(512) void stem_down_kernel(const StemDownArgs a) {
             const int Y = sy0 + sy, X = sx0 + sx;
             const bool inmap = p < SD_ROWS && (unsigned)Y < (unsigned)a.H1 && (unsigned)X < (unsigned)a.W1;
             inmask |= inmap ? (1u << gi) : 0u;
-            auto off = [&](int dh, int dw) -> unsigned {
-                const int hi = 2 * Y + dh, wi = 2 * X + dw;
-                const bool ok = inmap && (unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi;
-                return ok ? (unsigned)(((b * a.Hi + hi) * a.Wi + wi) * 8) : CY_OOB;
-            };
-            q0[gi] = load_b64(rsi, off(dh0, dw0));
-            q1[gi] = load_b64(rsi, off(dh1, dw1));
-            const unsigned o8 = off(1, 1);
-            q2[gi] = load_b64(rsi, fq == 0 ? o8 : CY_OOB);
+            // input pixel (2Y + dh, 2X + dw): with Hi = 2*H1 and Wi = 2*W1 only the -1 row / column can fall outside
+            const int hc = 2 * Y, wc = 2 * X;
+            const int base = ((b * a.Hi + hc) * a.Wi + wc) * 8;
+            const bool ok0 = inmap && ((hc + dh0) | (wc + dw0)) >= 0, ok1 = inmap && ((hc + dh1) | (wc + dw1)) >= 0;
+            q0[gi] = load_b64(rsi, ok0 ? (unsigned)(base + d0) : CY_OOB);
+            q1[gi] = load_b64(rsi, ok1 ? (unsigned)(base + d1) : CY_OOB);
+            q2[gi] = load_b64(rsi, (inmap && fq == 0) ? (unsigned)(base + d2) : CY_OOB);
         }
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) {
@@ -2023,10 +2025,11 @@ __global__ __launch_bounds__(512) void stem_down_kernel(const StemDownArgs a) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) acc[ni][m] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int pl = wm * 4 * SD_PW + fr;                      // LDS row of (first output row of this wave, tap (0,0), column fr)
+    if (!(a.dbg & 2))
 #pragma unroll
     for (int step = 0; step < 18; ++step) {
         const int tap = step >> 1, h = step & 1, kh = tap / 3, kw = tap % 3;
-        if (step + 3 < 18) load_wa(wa[(step + 3) & 3], step + 3);
+        if (step + SD_RING - 1 < 18) load_wa(wa[(step + SD_RING - 1) % SD_RING], step + SD_RING - 1);
         __builtin_amdgcn_sched_barrier(0);                   // (left alone the compiler sinks each load to just before its MFMAs)
         f16x8 xb[4];
 #pragma unroll
@@ -2039,7 +2042,7 @@ __global__ __launch_bounds__(512) void stem_down_kernel(const StemDownArgs a) {
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
             for (int m = 0; m < 4; ++m)
-                acc[ni][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[step & 3][ni], xb[m], acc[ni][m], 0, 0, 0);
+                acc[ni][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[step % SD_RING][ni], xb[m], acc[ni][m], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
 
@@ -2050,7 +2053,7 @@ __global__ __launch_bounds__(512) void stem_down_kernel(const StemDownArgs a) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         const int oy = oy0 + wm * 2 + (m >> 1), ox = ox0 + (m & 1) * 16 + fr;
-        if (oy >= a.Ho || ox >= a.Wo) continue;
+        if (oy >= a.Ho || ox >= a.Wo || (a.dbg & 4)) continue;
         const long pix = ((long)b * a.Ho + oy) * a.Wo + ox;
         f16x8 o0, o1;
 #pragma unroll
@@ -2071,12 +2074,14 @@ long stem_down_blocks(const StemDownArgs& a) {
 }
 
 hipError_t launch_stem_down(const StemDownArgs& a, hipStream_t s) {
+    if (a.Hi != 2 * a.H1 || a.Wi != 2 * a.W1) return hipErrorInvalidValue;
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(stem_down_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SD_LDS);
         attr_set = true;
     }
-    hipLaunchKernelGGL(stem_down_kernel, dim3((unsigned)stem_down_blocks(a)), dim3(512), SD_LDS, s, a);
+    StemDownArgs b2 = a; b2.dbg = getenv("CY_SD_DBG") ? atoi(getenv("CY_SD_DBG")) : 0;
+    hipLaunchKernelGGL(stem_down_kernel, dim3((unsigned)stem_down_blocks(a)), dim3(512), SD_LDS, s, b2);
     return hipGetLastError();
 }
 

@@ -42,6 +42,7 @@ struct StemDownArgs {
     const void* wgt32; uint32_t wgt32_bytes; const float* bias1;        // 3x3 s2 64->128 weights, 64-byte K chunks (pack_weights(..., 64))
     void* out; int out_ct, out_coff;
     int H1, W1, Ho, Wo;                                                 // stem map, output map
+    int dbg;                                                            // developer timing switches (CY_SD_DBG): skip a phase
 };
 
 struct PoolArgs {   // MaxPool2d(5,1,2) on a channel slice of an NHWC buffer, -inf padding
