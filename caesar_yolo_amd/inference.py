@@ -42,7 +42,8 @@ def shard(items, rank, world):
 # n*w plus a fixed launch/pipeline overhead per batch (measured on MI355X at world 8: 198 full tiles in one batch 28.7 ms,
 # in two 30.5 ms, in three 36.6 ms; full rate 7285 tiles/s -> 12-25 tile-equivalents per batch; small batches of
 # ragged tiles run well below the full rate).
-BATCH_OVERHEAD_TILES = 20.0
+BATCH_OVERHEAD_TILES = 26.0      # refit after the fused stem kernel: world 8 and 4 emulation (tools/emulate_ranks.py), 0.116 ms per tile
+SMALL_BATCH_EXTRA_TILES = 3.0
 
 
 def _rank_cost(segments, cost, batch):
@@ -51,6 +52,8 @@ def _rank_cost(segments, cost, batch):
     for shp, n in segments:
         if n:
             t += n * cost[shp] + BATCH_OVERHEAD_TILES * ((n + batch - 1) // batch)
+            if n < 64:
+                t += SMALL_BATCH_EXTRA_TILES           # the deep layers do not fill the chip: below the linear model
     return t
 
 
