@@ -77,11 +77,13 @@ const std::vector<std::vector<int>>& cached_neighbor_lists(const int* tiles, int
 }
 // Run f(lo, hi) over [0, n) on a few host threads (the two loops below are independent per element; at N GPUs this merge is
 // the serial tail of the step on rank 0, so its 1-2 ms matter).  Small inputs stay on the calling thread.
+constexpr int kMaxMergeThreads = 32;
 template <typename F>
 void parallel_ranges(int n, int min_per_thread, F f) {
-    static const int cap = getenv("CY_MERGE_THREADS") ? atoi(getenv("CY_MERGE_THREADS")) : 4;
-    int nt = (int)std::thread::hardware_concurrency();
-    if (nt > cap) nt = cap;
+    static const int forced = getenv("CY_MERGE_THREADS") ? atoi(getenv("CY_MERGE_THREADS")) : 0;   // an explicit count is taken as is
+    int nt = forced > 0 ? forced : (int)std::thread::hardware_concurrency();
+    if (forced <= 0 && nt > 4) nt = 4;
+    if (nt > kMaxMergeThreads) nt = kMaxMergeThreads;        // callers size their per-thread slots with this
     if (nt < 1) nt = 1;
     if (n / (min_per_thread > 0 ? min_per_thread : 1) < nt) nt = n / (min_per_thread > 0 ? min_per_thread : 1);
     if (nt <= 1) { f(0, n, 0); return; }
@@ -153,7 +155,7 @@ extern "C" int cy_merge_edge_sources(const double* rec, int n, const int* tiles,
     for (int k = 0; k < N; ++k) { const double* r = rec + 8 * tbm[k]; box[4 * k] = r[0]; box[4 * k + 1] = r[1]; box[4 * k + 2] = r[2]; box[4 * k + 3] = r[3]; tof[k] = (int)r[6]; }
     // ranges of i on a few threads, each with its own pair list; concatenated in range order they are in the same
     // lexicographic order a single loop produces
-    std::vector<std::vector<std::pair<int, int>>> part(8);
+    std::vector<std::vector<std::pair<int, int>>> part(kMaxMergeThreads);
     parallel_ranges(N, 1024, [&](int lo, int hi, int slot) {
         auto& out_pairs = part[slot];
         for (int i = lo; i < hi; ++i) {

@@ -103,3 +103,39 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(L, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(L.CyError):
         L.load()
+
+
+def test_merge_is_independent_of_thread_count():
+    """cy_merge_edge_sources splits its pair search over host threads (CY_MERGE_THREADS, read once per process): same
+    catalog for 1, 4 and 16 threads on 40k synthetic detections (16 used to overrun the per-thread pair lists)."""
+    import subprocess, sys, hashlib
+    code = r'''
+import sys, hashlib
+import numpy as np
+sys.path.insert(0, %r)
+from caesar_yolo_amd import utils
+from caesar_yolo_amd.inference import merge_records
+grid = utils.generate_tiles(0, 8191, 0, 8191, 512, 512, 0.8, 0.8)
+rng = np.random.default_rng(7)
+det, dt = [], []
+for t, (x0, x1, y0, y1) in enumerate(grid):
+    n = 100
+    nx, ny = x1 - x0, y1 - y0
+    cx, cy = rng.uniform(0, nx, n), rng.uniform(0, ny, n)
+    w, h = rng.uniform(4, 40, n), rng.uniform(4, 40, n)
+    b = np.stack([np.clip(cx - w, 0, nx), np.clip(cy - h, 0, ny), np.clip(cx + w, 0, nx), np.clip(cy + h, 0, ny),
+                  rng.uniform(0.7, 1.0, n), rng.integers(0, 5, n)], 1)
+    det.append(b); dt.append(np.full(n, t))
+det = np.ascontiguousarray(np.concatenate(det), np.float32); dt = np.ascontiguousarray(np.concatenate(dt), np.int32)
+out = merge_records(det, dt, grid)
+print(len(det), out.shape[0], hashlib.sha256(np.ascontiguousarray(out).tobytes()).hexdigest())
+''' % ROOT
+    res = set()
+    for nt in ("1", "4", "16"):
+        env = dict(os.environ, CY_MERGE_THREADS=nt)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.add(r.stdout.strip())
+    assert len(res) == 1, res
+    n_in, n_out = [int(v) for v in res.pop().split()[:2]]
+    assert n_in >= 40000 and 0 < n_out < n_in
