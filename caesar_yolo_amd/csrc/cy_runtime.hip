@@ -26,6 +26,8 @@ struct cy_ctx {
     std::vector<DevConv> dconv;
     // workspace
     char* ws = nullptr; size_t ws_bytes = 0;           // activations
+    // second workspace + stream: cy_detect_tiles runs batches of 64..239 tiles as two concurrent half-batches (forward_split)
+    char* ws2 = nullptr; size_t ws2_bytes = 0; hipStream_t s_fwd2 = nullptr; hipEvent_t ev_split[2] = {nullptr, nullptr};
     std::vector<size_t> toff; std::vector<size_t> tbytes;   // per tensor, for the last forward geometry
     int lastB = 0, lastH = 0, lastW = 0;
     // stage buffers (sized at load for max_batch), two sets: cy_detect_tiles software-pipelines consecutive batches
@@ -45,6 +47,7 @@ struct cy_ctx {
     unsigned long batches = 0;                          // cy_detect_tiles calls since load / flush
     // optional per-launch timing of the forward ops (hipEvents on the caller's stream)
     bool profiling = false;
+    bool split_last = false;                             // the last forward ran as two half-batches (debug reads see only one)
     bool stem_fused_last = false;                        // the last forward ran model.0 + model.1 as one kernel (no model.0 tensor)
     int prof_stride = 1; unsigned long fwd_calls = 0;   // profiling on: every prof_stride-th cy_forward call is timed
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
@@ -79,6 +82,10 @@ void free_all(cy_ctx* c) {
     c->dconv.clear();
     if (c->ws) hipFree(c->ws);
     c->ws = nullptr;
+    if (c->ws2) hipFree(c->ws2);
+    c->ws2 = nullptr; c->ws2_bytes = 0;
+    if (c->s_fwd2) { hipStreamDestroy(c->s_fwd2); c->s_fwd2 = nullptr; }
+    for (auto& e : c->ev_split) if (e) { hipEventDestroy(e); e = nullptr; }
     for (auto& b : c->sb) {
         void* ptrs[] = {b.netin, b.pred, b.cand, b.cand_anchor, b.cand_count, b.keys, b.det, b.det_anchor, b.det_count,
                         b.merge_err, b.out_src, b.pre_params, b.pre_histeq, b.pre_scratch};
@@ -270,7 +277,7 @@ int upload_weights(cy_ctx* c, const void* buf, size_t nbytes) {
     return CY_OK;
 }
 
-int layout_tensors(cy_ctx* c, int B, int H, int W) {
+int layout_tensors(cy_ctx* c, int B, int H, int W, size_t capacity) {
     const size_t es = esize(c->prec);
     c->toff.assign(c->plan.tensors.size(), 0);
     c->tbytes.assign(c->plan.tensors.size(), 0);
@@ -282,7 +289,7 @@ int layout_tensors(cy_ctx* c, int B, int H, int W) {
         off += align_up(b, 256);
         if (b >= 0xFFFFFF00ull) return fail(c, CY_ERR_ARG, "a tensor exceeds the 4 GiB buffer-addressing limit; lower the batch");
     }
-    if (off > c->ws_bytes) return fail(c, CY_ERR_ARG, "batch/shape exceeds the workspace sized at cy_create");
+    if (off > capacity) return fail(c, CY_ERR_ARG, "batch/shape exceeds the workspace sized at cy_create");
     c->lastB = B; c->lastH = H; c->lastW = W;
     return CY_OK;
 }
@@ -376,24 +383,63 @@ int cy_mosaic_prepare(cy_ctx* c, float* d_data, size_t n, int big_endian, void* 
     return CY_OK;
 }
 
+static int forward_on(cy_ctx* c, const void* d_netin, int B, int H, int W, float* d_pred, hipStream_t s, char* ws, size_t ws_cap,
+                      bool may_profile);
+
 int cy_forward(cy_ctx* c, const void* d_netin, int B, int H, int W, float* d_pred, void* stream) {
     if (!c || !c->loaded) return fail(c, CY_ERR_STATE, "weights not loaded");
-    if (!d_netin || !d_pred || B < 1 || H % 32 || W % 32 || H < 32 || W < 32) return fail(c, CY_ERR_ARG, "bad forward arguments");
-    int rc = layout_tensors(c, B, H, W);
+    c->split_last = false;
+    return forward_on(c, d_netin, B, H, W, d_pred, (hipStream_t)stream, c->ws, c->ws_bytes, true);
+}
+
+// The forward of one batch as TWO half-batches on two streams (own workspace each).  Every layer is one kernel launch
+// whose last round of workgroups leaves part of the chip idle, and kernels of one stream cannot overlap: the other half's
+// kernels fill those tails.  Measured on MI355X (tools/concurrent_forward.py, forward only): -6.8 % at 208 tiles, -3.7 % at
+// 224, -1.3 % at 254.  Used for 64..239 tiles (the per-rank shares at N >= 2); a full batch stays on one stream, so that the
+// per-launch event timing of bench.py at N = 1 means exclusive use of the GPU.  CY_DUAL_FORWARD: 0 off, 2 from 2 tiles on.
+static int forward_split(cy_ctx* c, const void* d_netin, int B, int H, int W, float* d_pred, hipStream_t sm) {
+    const char* e = getenv("CY_DUAL_FORWARD");
+    const int mode = e ? atoi(e) : 1;
+    const bool split = c->prec == PREC_F16 && mode != 0 && B >= 2 && (mode > 1 || (B >= 64 && B < 240));
+    c->split_last = split;
+    if (!split) return forward_on(c, d_netin, B, H, W, d_pred, sm, c->ws, c->ws_bytes, true);
+    if (!c->ws2) {
+        c->ws2_bytes = c->ws_bytes / 2 + (1u << 20);        // the second half is never the larger one
+        HIPCHK(c, hipMalloc(&c->ws2, c->ws2_bytes));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->s_fwd2, hipStreamNonBlocking));
+        for (auto& ev : c->ev_split) HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    const int h = B - B / 2;
+    const size_t in_half = (size_t)h * H * W * 4 * esize(c->prec);
+    const size_t pred_half = (size_t)h * cy_num_anchors(H, W) * (64 + c->plan.nc);
+    HIPCHK(c, hipEventRecord(c->ev_split[0], sm));           // everything the forward waits for is already queued on sm
+    HIPCHK(c, hipStreamWaitEvent(c->s_fwd2, c->ev_split[0], 0));
+    int rc = forward_on(c, d_netin, h, H, W, d_pred, sm, c->ws, c->ws_bytes, true);
     if (rc) return rc;
-    hipStream_t s = (hipStream_t)stream;
+    rc = forward_on(c, (const char*)d_netin + in_half, B - h, H, W, d_pred + pred_half, c->s_fwd2, c->ws2, c->ws2_bytes, false);
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(c->ev_split[1], c->s_fwd2));
+    HIPCHK(c, hipStreamWaitEvent(sm, c->ev_split[1], 0));
+    return CY_OK;
+}
+
+static int forward_on(cy_ctx* c, const void* d_netin, int B, int H, int W, float* d_pred, hipStream_t s, char* ws, size_t ws_cap,
+                      bool may_profile) {
+    if (!d_netin || !d_pred || B < 1 || H % 32 || W % 32 || H < 32 || W < 32) return fail(c, CY_ERR_ARG, "bad forward arguments");
+    int rc = layout_tensors(c, B, H, W, ws_cap);
+    if (rc) return rc;
     const Plan& p = c->plan;
     const size_t es = esize(c->prec);
     const int A = cy_num_anchors(H, W);
     int a_off[3], acc = 0;
     for (int l = 0; l < 3; ++l) { a_off[l] = acc; acc += (H >> (3 + l)) * (W >> (3 + l)); }
-    auto tptr = [&](int t) -> char* { return t == 0 ? (char*)const_cast<void*>(d_netin) : c->ws + c->toff[t]; };
+    auto tptr = [&](int t) -> char* { return t == 0 ? (char*)const_cast<void*>(d_netin) : ws + c->toff[t]; };
     auto stamp = [&]() -> size_t {
         if (c->ev_used == c->ev_pool.size()) { hipEvent_t e; hipEventCreate(&e); c->ev_pool.push_back(e); }
         hipEventRecord(c->ev_pool[c->ev_used], s);
         return c->ev_used++;
     };
-    const bool prof_now = c->profiling && (c->fwd_calls++ % (unsigned long)c->prof_stride) == 0;
+    const bool prof_now = may_profile && c->profiling && (c->fwd_calls++ % (unsigned long)c->prof_stride) == 0;
     size_t ev_prev = prof_now ? stamp() : 0;
     int cur_conv = -1;
     auto prof_done = [&](int kind, double flops) {
@@ -597,6 +643,7 @@ int cy_profile_layers(cy_ctx* c, cy_prof_entry* out, int cap) {
 int cy_debug_read_conv(cy_ctx* c, const char* conv_name, float* h_out, size_t cap, int* dims4) {
     if (!c || !c->loaded || !conv_name || !h_out) return fail(c, CY_ERR_ARG, "bad arguments");
     if (c->lastB == 0) return fail(c, CY_ERR_STATE, "no forward has run");
+    if (c->split_last) return fail(c, CY_ERR_STATE, "the last batch ran as two half-batches (CY_DUAL_FORWARD=0 keeps it in one workspace)");
     const Plan& p = c->plan;
     for (const Op& o : p.ops) {
         if (o.conv < 0 || p.convs[o.conv].name != conv_name) continue;      // pool and attention ops carry no convolution
@@ -791,7 +838,7 @@ int cy_detect_tiles(cy_ctx* c, const float* d_mosaic, int MH, int MW, const int*
     HIPCHK(c, hipEventRecord(c->ev_pre[sl], c->s_pre));
     HIPCHK(c, hipStreamWaitEvent(sm, c->ev_pre[sl], 0));
     if (reuse) HIPCHK(c, hipStreamWaitEvent(sm, c->ev_post[sl], 0));
-    rc = cy_forward(c, c->S().netin, B, lb.H, lb.W, c->S().pred, sm);
+    rc = forward_split(c, c->S().netin, B, lb.H, lb.W, c->S().pred, sm);
     if (rc) { c->slot = 0; return rc; }
     HIPCHK(c, hipEventRecord(c->ev_fwd[sl], sm));
     HIPCHK(c, hipStreamWaitEvent(c->s_post, c->ev_fwd[sl], 0));

@@ -52,15 +52,11 @@ class HipDetector(object):
         self.ctx = C.c_void_p()
         L.check(self.lib.cy_create(self.device, C.byref(cfg), C.byref(self.ctx)))
         L.check(self.lib.cy_load_weights(self.ctx, os.fsencode(weights_path)), self.ctx)
-        self._wpath, self._max_hw, self._ctx2, self._s2 = weights_path, m, None, None
         nc = self.lib.cy_num_classes(self.ctx)
         self.names = {i: self.lib.cy_class_name(self.ctx, i).decode() for i in range(nc)}
         self.nc = nc
 
     def close(self):
-        if getattr(self, "_ctx2", None):
-            self.lib.cy_destroy(self._ctx2)
-            self._ctx2 = None
         if getattr(self, "ctx", None):
             self.lib.cy_destroy(self.ctx)
             self.ctx = None
@@ -118,38 +114,10 @@ class HipDetector(object):
         self._chk(self.lib.cy_letterbox_pack(self.ctx, self._p(planes), B, h0, w0, imgsz, self._p(netin), self._stream()))
         return netin, lb
 
-    # Two half-batches on two streams (second context = second workspace): every layer is one kernel launch whose last
-    # round of workgroups leaves part of the chip idle, and kernels of ONE stream cannot overlap; with two streams the
-    # other half's kernels fill those tails.  Measured on MI355X (tools/concurrent_forward.py), forward-only:
-    # -6.8 % at 208 tiles, -3.7 % at 224, -1.3 % at 254.  Used below 240 tiles (the shares of N >= 2 ranks); a full
-    # batch stays on one stream, where the per-launch event timing of bench.py means exclusive use of the GPU.
-    DUAL_MIN, DUAL_BELOW = 64, 240
-
-    def _dual(self, B):
-        env = os.environ.get("CY_DUAL_FORWARD", "1")
-        if env == "0" or self.precision != L.F16:
-            return False
-        return env == "2" or self.DUAL_MIN <= B < self.DUAL_BELOW
-
     def forward(self, netin):
         B, H, Wd, _ = netin.shape
         A = self.lib.cy_num_anchors(H, Wd)
         pred = torch.empty((B, A, 64 + self.nc), dtype=torch.float32, device=self.tdev)
-        if B >= 2 and self._dual(B):
-            if self._ctx2 is None:
-                cfg = L.cy_config(self.precision, (self.max_batch + 1) // 2, self._max_hw, self._max_hw, 0)
-                ctx2 = C.c_void_p()
-                L.check(self.lib.cy_create(self.device, C.byref(cfg), C.byref(ctx2)))
-                L.check(self.lib.cy_load_weights(ctx2, os.fsencode(self._wpath)), ctx2)
-                self._ctx2, self._s2 = ctx2, torch.cuda.Stream(self.tdev)
-            h = B - B // 2
-            cur = torch.cuda.current_stream(self.tdev)
-            self._s2.wait_stream(cur)                                    # the input is ready on the caller's stream
-            self._chk(self.lib.cy_forward(self.ctx, self._p(netin), h, H, Wd, self._p(pred), self._stream()))
-            L.check(self.lib.cy_forward(self._ctx2, self._p(netin[h:]), B - h, H, Wd, self._p(pred[h:]),
-                                        C.c_void_p(self._s2.cuda_stream)), self._ctx2)
-            cur.wait_stream(self._s2)
-            return pred
         self._chk(self.lib.cy_forward(self.ctx, self._p(netin), B, H, Wd, self._p(pred), self._stream()))
         return pred
 

@@ -120,24 +120,3 @@ def test_other_scales_fp32(scale, nc):
         err = float((pred.cpu() - raw).abs().max())
         assert err <= tol * max(1.0, float(raw.abs().max())), (scale, prec, err)
         det.close()
-
-
-def test_dual_stream_forward_matches_single_stream(monkeypatch):
-    """HipDetector.forward splits batches of 64..239 tiles into two halves on two streams (second context); forced here on
-    a batch of 4 (halves 2 + 2): same head output as one stream, up to the fp16 kernel choice that depends on the batch."""
-    det = detector("fp16")
-    base = _tile("big512", 256, 256)
-    imgs = [base, base[::-1].copy(), base[:, ::-1].copy(), base[::-1, ::-1].copy()]
-    x, raw, _ = _oracle_forward(imgs, 256)
-    xin = netin_from_chw(x, det.dtype)
-    monkeypatch.setenv("CY_DUAL_FORWARD", "0")
-    one = det.forward(xin).cpu()
-    monkeypatch.setenv("CY_DUAL_FORWARD", "2")
-    two = det.forward(xin)
-    torch.cuda.synchronize()
-    two = two.cpu()
-    assert det._ctx2 is not None
-    sc = max(1.0, float(raw.abs().max()))
-    assert float((one - raw).abs().max()) <= 6e-2 * sc
-    assert float((two - raw).abs().max()) <= 6e-2 * sc
-    assert float((two - one).abs().max()) <= 2e-2 * sc

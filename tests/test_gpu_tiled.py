@@ -145,3 +145,32 @@ def test_predict_tiles_batched_entry():
     with pytest.raises(ValueError):
         model.predict_tiles(mosaic, [(0, 256, 0, 256), (0, 200, 0, 256)], cfg, imgsz=256)
     assert model.predict_tiles(mosaic, [], cfg) == []
+
+
+def test_split_forward_gives_the_same_detections(monkeypatch):
+    """cy_detect_tiles runs batches of 64..239 tiles as two half-batches on two streams (second workspace); forced here on
+    a batch of 5 (3 + 2): same per-tile detections as the single-stream forward (fp16 context)."""
+    from caesar_yolo_amd.model import YOLO
+    from caesar_yolo_amd import preprocessing as PP
+    img = np.load(os.path.join(ROOT, "tests/golden/mosaic_c.npz"))["img"].astype(np.float32)
+    model = YOLO(seeded_weights()[0], precision="fp16", max_batch=8, max_imgsz=256, device=0)
+    eng = model.engine()
+    mosaic = eng.mosaic_to_device(img)
+    cfg = PP.DataPreprocessor([PP.ZScaleTransformer([0.25] * 3), PP.MinMaxNormalizer(0, 255)]).program()
+    coords = [(0, 256, 0, 256), (256, 512, 0, 256), (512, 768, 0, 256), (128, 384, 128, 384), (600, 856, 400, 656)]
+    out = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("CY_DUAL_FORWARD", mode)
+        res = model.predict_tiles(mosaic, coords, cfg, imgsz=256, conf=0.3, iou=IOU,      # (nothing reaches 0.7 on these tiles)
+                                  merge_overlap_iou_thr_soft=SOFT, merge_overlap_iou_thr_hard=HARD)
+        out[mode] = [None if r is None else (r.boxes.xyxy.cpu().numpy(), r.boxes.conf.cpu().numpy(), r.boxes.cls.cpu().numpy())
+                     for r in res]
+    assert sum(len(o[1]) for o in out["0"] if o is not None) > 0
+    for a, b in zip(out["0"], out["2"]):
+        assert (a is None) == (b is None)
+        if a is None:
+            continue
+        assert len(a[1]) == len(b[1])
+        np.testing.assert_allclose(a[1], b[1], atol=5e-3)
+        np.testing.assert_array_equal(a[2], b[2])
+        np.testing.assert_allclose(a[0], b[0], atol=0.5)
