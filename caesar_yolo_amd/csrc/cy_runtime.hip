@@ -397,18 +397,23 @@ int cy_forward(cy_ctx* c, const void* d_netin, int B, int H, int W, float* d_pre
 // kernels fill those tails.  Measured on MI355X (tools/concurrent_forward.py, forward only): -6.8 % at 208 tiles, -3.7 % at
 // 224, -1.3 % at 254.  Used for 64..239 tiles (the per-rank shares at N >= 2); a full batch stays on one stream, so that the
 // per-launch event timing of bench.py at N = 1 means exclusive use of the GPU.  CY_DUAL_FORWARD: 0 off, 2 from 2 tiles on.
+static int ensure_second_workspace(cy_ctx* c) {
+    if (c->ws2) return CY_OK;
+    c->ws2_bytes = c->ws_bytes / 2 + (1u << 20);            // the second half is never the larger one
+    HIPCHK(c, hipMalloc(&c->ws2, c->ws2_bytes));
+    HIPCHK(c, hipStreamCreateWithFlags(&c->s_fwd2, hipStreamNonBlocking));
+    for (auto& ev : c->ev_split) HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    return CY_OK;
+}
+static int dual_mode() { const char* e = getenv("CY_DUAL_FORWARD"); return e ? atoi(e) : 1; }
+
 static int forward_split(cy_ctx* c, const void* d_netin, int B, int H, int W, float* d_pred, hipStream_t sm) {
-    const char* e = getenv("CY_DUAL_FORWARD");
-    const int mode = e ? atoi(e) : 1;
+    const int mode = dual_mode();
     const bool split = c->prec == PREC_F16 && mode != 0 && B >= 2 && (mode > 1 || (B >= 64 && B < 240));
     c->split_last = split;
     if (!split) return forward_on(c, d_netin, B, H, W, d_pred, sm, c->ws, c->ws_bytes, true);
-    if (!c->ws2) {
-        c->ws2_bytes = c->ws_bytes / 2 + (1u << 20);        // the second half is never the larger one
-        HIPCHK(c, hipMalloc(&c->ws2, c->ws2_bytes));
-        HIPCHK(c, hipStreamCreateWithFlags(&c->s_fwd2, hipStreamNonBlocking));
-        for (auto& ev : c->ev_split) HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    }
+    int rc0 = ensure_second_workspace(c);
+    if (rc0) return rc0;
     const int h = B - B / 2;
     const size_t in_half = (size_t)h * H * W * 4 * esize(c->prec);
     const size_t pred_half = (size_t)h * cy_num_anchors(H, W) * (64 + c->plan.nc);
@@ -836,11 +841,22 @@ int cy_detect_tiles(cy_ctx* c, const float* d_mosaic, int MH, int MW, const int*
     rc = cy_preproc(c, d_mosaic, MH, MW, h_tiles, B, th, tw, imgsz, cfg, c->S().netin, d_status, c->s_pre);
     if (rc) { c->slot = 0; return rc; }
     HIPCHK(c, hipEventRecord(c->ev_pre[sl], c->s_pre));
-    HIPCHK(c, hipStreamWaitEvent(sm, c->ev_pre[sl], 0));
-    if (reuse) HIPCHK(c, hipStreamWaitEvent(sm, c->ev_post[sl], 0));
-    rc = forward_split(c, c->S().netin, B, lb.H, lb.W, c->S().pred, sm);
+    // A small batch (the ragged edge classes of a mosaic: 1-39 tiles) does not fill the chip on the deep layers; its
+    // forward goes to the second stream + workspace, where it runs BESIDE the neighbouring batches' forward instead of after it.
+    bool side = false;
+    if (c->prec == PREC_F16 && dual_mode() == 1 && B < 64 && c->batches >= 1) {
+        rc = ensure_second_workspace(c);
+        if (rc) { c->slot = 0; return rc; }
+        side = (tensor_elems_per_tile(c->plan, lb.H, lb.W) * (size_t)B * esize(c->prec) + 256 * c->plan.tensors.size()) <= c->ws2_bytes;
+    }
+    hipStream_t sf = side ? c->s_fwd2 : sm;
+    if (side) HIPCHK(c, hipStreamWaitEvent(sf, c->ev_call, 0));
+    HIPCHK(c, hipStreamWaitEvent(sf, c->ev_pre[sl], 0));
+    if (reuse) HIPCHK(c, hipStreamWaitEvent(sf, c->ev_post[sl], 0));
+    if (side) { c->split_last = true; rc = forward_on(c, c->S().netin, B, lb.H, lb.W, c->S().pred, sf, c->ws2, c->ws2_bytes, false); }
+    else rc = forward_split(c, c->S().netin, B, lb.H, lb.W, c->S().pred, sm);
     if (rc) { c->slot = 0; return rc; }
-    HIPCHK(c, hipEventRecord(c->ev_fwd[sl], sm));
+    HIPCHK(c, hipEventRecord(c->ev_fwd[sl], sf));
     HIPCHK(c, hipStreamWaitEvent(c->s_post, c->ev_fwd[sl], 0));
     rc = cy_decode_nms(c, c->S().pred, B, lb.H, lb.W, th, tw, conf, iou, c->S().det, c->S().det_anchor, c->S().det_count, c->s_post);
     if (!rc) rc = cy_iou_merge(c, c->S().det, c->S().det_count, B, conf, soft, hard, d_out, d_out_count, nullptr, c->s_post);
