@@ -1392,7 +1392,7 @@ static hipError_t launch_wide(const ConvArgs& a, hipStream_t s) {
 //   per 64-channel K chunk and wave: NB DMA pieces + 2*MI register loads for 8*NB*MI MFMAs (NB=4, MI=2: 8 for 64).
 // Also handles the two-segment input (nearest-x2 upsample + concat) of layers 12 and 15: per-lane addresses anyway.
 template <int NB, int MI, int RING, bool K3>
-__global__ __launch_bounds__(512) void conv1x1_direct_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(512, (NB == 2 && MI == 2 && RING == 2) ? 2 : 1) void conv1x1_direct_kernel(const ConvArgs a) {
     constexpr int NW = 8, BN = 64 * NB, BM = NW * MI * 16, W_BYTES = BN * 128, DIST = RING - 1;
     constexpr int WPW = BN / 8 / NW, APW = 2 * MI, PER = WPW + APW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1689,7 +1689,8 @@ int conv_variant(Precision p, const ConvArgs& a) {
         ((a.k == 1 && a.s == 1 && (a.c1 == 0 || a.c0 % 64 == 0)) || (a.k == 3 && a.s == 2 && a.c1 == 0 && !a.up0 && (a.Cin >= 128 || pad64(a.Cout) < 256) && s2_direct()))) {
         const char* e = getenv("CY_DIRECT_MIN_BLOCKS");
         const long min_blocks = e ? atol(e) : 256;
-        const int bn = pad64(a.Cout) >= 256 ? 256 : 128;
+        static const int bn_force = getenv("CY_DIRECT_BN") ? atoi(getenv("CY_DIRECT_BN")) : 0;      // tuning knob
+        const int bn = bn_force == 128 && a.k == 1 ? 128 : (pad64(a.Cout) >= 256 ? 256 : 128);
         const long blocks = (((long)a.B * a.Ho * a.Wo + 255) / 256) * ((pad64(a.Cout) + bn - 1) / bn);
         if (min_blocks >= 0 && blocks >= min_blocks) return bn == 256 ? CONV_DIRECT_256 : CONV_DIRECT_128;
     }
@@ -1718,6 +1719,9 @@ hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s) {
         case CONV_WIDE_DUAL: return launch_wide<2, true>(a, s);
         case CONV_DIRECT_256: return a.k == 3 ? launch_direct<4, 2, 3, true>(a, s) : launch_direct<4, 2, 3, false>(a, s);
         case CONV_DIRECT_128:     // strided 3x3 (model.1): 64 px per wave, so every weight fragment feeds four MFMAs (-8 % vs 32 px)
+            // 1x1 with a 128-channel tile = the HBM-bound layers (model.2.cv1/cv2): two workgroups per CU (126 VGPRs, one chunk
+            // ahead) overlap each other's prologue/epilogue: -12 % against one workgroup with a 4-chunk ring
+            if (a.k != 3 && !(getenv("CY_D128_V") && atoi(getenv("CY_D128_V")) == 0)) return launch_direct<2, 2, 2, false>(a, s);
             return a.k == 3 ? launch_direct<2, 4, 2, true>(a, s) : launch_direct<2, 2, 4, false>(a, s);
         case CONV_GENERIC_64: return p == PREC_F16 ? launch_t<f16, 4, 1, 2>(a, s) : launch_t<float, 4, 1, 2>(a, s);
         default: return p == PREC_F16 ? launch_t<f16, 2, 2, 4>(a, s) : launch_t<float, 2, 2, 4>(a, s);
