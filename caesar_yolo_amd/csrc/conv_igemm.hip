@@ -1392,7 +1392,7 @@ static hipError_t launch_wide(const ConvArgs& a, hipStream_t s) {
 //   per 64-channel K chunk and wave: NB DMA pieces + 2*MI register loads for 8*NB*MI MFMAs (NB=4, MI=2: 8 for 64).
 // Also handles the two-segment input (nearest-x2 upsample + concat) of layers 12 and 15: per-lane addresses anyway.
 template <int NB, int MI, int RING, bool K3>
-__global__ __launch_bounds__(512, (NB == 2 && MI == 2 && RING == 2) ? 2 : 1) void conv1x1_direct_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(512, (NB * MI <= 4 && RING == 2) ? 2 : 1) void conv1x1_direct_kernel(const ConvArgs a) {
     constexpr int NW = 8, BN = 64 * NB, BM = NW * MI * 16, W_BYTES = BN * 128, DIST = RING - 1;
     constexpr int WPW = BN / 8 / NW, APW = 2 * MI, PER = WPW + APW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1717,7 +1717,13 @@ hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s) {
         case CONV_WIDE_128: return launch_wide<2>(a, s);
         case CONV_WIDE_64: return launch_wide<1>(a, s);
         case CONV_WIDE_DUAL: return launch_wide<2, true>(a, s);
-        case CONV_DIRECT_256: return a.k == 3 ? launch_direct<4, 2, 3, true>(a, s) : launch_direct<4, 2, 3, false>(a, s);
+        case CONV_DIRECT_256: {
+            // tuning knob, off: 128 px x 256 ch tiles with two workgroups per CU for Cin <= CY_D256_V.  Measured at batch 256: 2-12 %
+            // SLOWER on every 256-channel 1x1 layer but model.4.cv1 (-4 %): twice the weight pieces per MFMA cost more than the overlap buys
+            static const int v256 = getenv("CY_D256_V") ? atoi(getenv("CY_D256_V")) : 0;
+            if (a.k != 3 && v256 > 0 && a.Cin <= v256) return launch_direct<4, 1, 2, false>(a, s);
+            return a.k == 3 ? launch_direct<4, 2, 3, true>(a, s) : launch_direct<4, 2, 3, false>(a, s);
+        }
         case CONV_DIRECT_128:     // strided 3x3 (model.1): 64 px per wave, so every weight fragment feeds four MFMAs (-8 % vs 32 px)
             // 1x1 with a 128-channel tile = the HBM-bound layers (model.2.cv1/cv2): two workgroups per CU (126 VGPRs, one chunk
             // ahead) overlap each other's prologue/epilogue: -12 % against one workgroup with a 4-chunk ring
