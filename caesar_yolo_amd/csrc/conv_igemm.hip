@@ -1722,6 +1722,7 @@ hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s) {
             // SLOWER on every 256-channel 1x1 layer but model.4.cv1 (-4 %): twice the weight pieces per MFMA cost more than the overlap buys
             static const int v256 = getenv("CY_D256_V") ? atoi(getenv("CY_D256_V")) : 0;
             if (a.k != 3 && v256 > 0 && a.Cin <= v256) return launch_direct<4, 1, 2, false>(a, s);
+            // (a 4-slot ring for this tile: 256 VGPRs with spills, 3-10 % slower)
             return a.k == 3 ? launch_direct<4, 2, 3, true>(a, s) : launch_direct<4, 2, 3, false>(a, s);
         }
         case CONV_DIRECT_128:     // strided 3x3 (model.1): 64 px per wave, so every weight fragment feeds four MFMAs (-8 % vs 32 px)
