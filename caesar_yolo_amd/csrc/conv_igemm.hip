@@ -1145,12 +1145,15 @@ static hipError_t launch_halo2(const ConvArgs& a, hipStream_t s) {
 // per wave and stage, 32 MFMAs per wave between barriers.
 // DUAL = true: maps at most 16 pixels wide (the stride-32 level of a 512-px tile): the 32 patch columns are the 16 columns of
 // TWO consecutive images, each with its own left/right halo column (patch rows of 36 instead of 34 pixels).
-template <bool TAIL, int WN, bool DUAL = false>
+template <bool TAIL, int WN, bool DUAL = false, int TPS = 2>
 __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
+    // TPS = taps per stage (between two barriers): 2, or 3 (WN = 2 only: six stages of 96 MFMAs per slab pair, 152 KiB of LDS)
+    static_assert(TPS == 2 || (TPS == 3 && WN == 2), "three taps per stage: 128-channel variant only");
+    constexpr int NST = 18 / TPS;
     constexpr int TH = 16, TW = 32, NW = 8, BN = 64 * WN, PWID = DUAL ? 36 : TW + 2, HALF = DUAL ? 18 : 16;
-    constexpr int RPW = TH / (NW / WN), MIW = 2 * RPW, WPS = WN;          // image rows / pixel fragments per wave; weight pieces per wave and stage
+    constexpr int RPW = TH / (NW / WN), MIW = 2 * RPW, WPS = WN == 2 ? TPS : 1;   // image rows / pixel fragments per wave; weight pieces per wave and stage
     constexpr int PR = (TH + 2) * PWID, NPC = (PR + 15) / 16, PROUNDS = (NPC + NW - 1) / NW;
-    constexpr int P_BYTES = PROUNDS * NW * 1024, SLAB = BN * 64, W_BYTES = 2 * SLAB, RING = 3;
+    constexpr int P_BYTES = PROUNDS * NW * 1024, SLAB = BN * 64, W_BYTES = TPS * SLAB, RING = 3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const Pbuf = smem;
     char* const Wbuf = smem + 2 * P_BYTES;
@@ -1195,10 +1198,10 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
         for (int j = 0; j < PROUNDS; ++j)                    // uniform part in soffset: not range-checked, so the OOB sentinel of
             dma_piece(rs0, (lds_ptr_t*)(Pbuf + buf * P_BYTES + (j * NW + wave) * 1024), poff[j], slab * 64);   // a lane survives it
     };
-    auto dma_stage = [&](int ring, int slab0, int u0) {     // taps u0, u0+1 of the pair starting at slab slab0 (u in 0..17)
+    auto dma_stage = [&](int ring, int slab0, int u0) {     // taps u0 .. u0+TPS-1 of the pair starting at slab slab0 (u in 0..17)
         if constexpr (WN == 2) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < TPS; ++t) {
                 const int u = u0 + t, sl = slab0 + u / 9, tap = u % 9;
                 dma_piece(rsw, (lds_ptr_t*)(Wbuf + ring * W_BYTES + t * SLAB + wave * 1024), woff, (sl * 9 + tap) * cpad * 64);
             }
@@ -1245,10 +1248,32 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
             for (int m = 0; m < 4; ++m)
                 acc[ni][half * 4 + m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ni], x[m], acc[ni][half * 4 + m], 0, 0, 0);
     };
-    auto stage_compute = [&](int st) {                       // taps u = 2*st, 2*st+1 of the current slab pair
-        const int u0 = 2 * st, u1 = u0 + 1, t0 = u0 % 9, t1 = u1 % 9;
+    auto stage_compute = [&](int st) {                       // taps u = TPS*st .. of the current slab pair
+        const int u0 = TPS * st, u1 = u0 + 1, t0 = u0 % 9, t1 = u1 % 9;
         const int p0 = (u0 / 9) * P_BYTES, p1 = (u1 / 9) * P_BYTES, w0 = (st % 3) * W_BYTES, w1 = w0 + SLAB;
-        if constexpr (WN == 2) {
+        if constexpr (TPS == 3) {                             // six half-steps, fragments double-buffered one half-step ahead
+            const int u2 = u0 + 2, t2 = u2 % 9, p2 = (u2 / 9) * P_BYTES, w2 = w1 + SLAB;
+            load_w(wb[0], w0);
+            load_x(xa[0], p0, t0 / 3, t0 % 3, 0);
+            load_x(xa[1], p0, t0 / 3, t0 % 3, 1);
+            mma(wb[0], xa[0], 0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_w(wb[1], w1);
+            load_x(xa[0], p1, t1 / 3, t1 % 3, 0);
+            mma(wb[0], xa[1], 1);
+            __builtin_amdgcn_sched_barrier(0);
+            load_x(xa[1], p1, t1 / 3, t1 % 3, 1);
+            mma(wb[1], xa[0], 0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_w(wb[0], w2);
+            load_x(xa[0], p2, t2 / 3, t2 % 3, 0);
+            mma(wb[1], xa[1], 1);
+            __builtin_amdgcn_sched_barrier(0);
+            load_x(xa[1], p2, t2 / 3, t2 % 3, 1);
+            mma(wb[0], xa[0], 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!TAIL) mma(wb[0], xa[1], 1);
+        } else if constexpr (WN == 2) {
             load_w(wb[0], w0);
             load_x(xa[0], p0, t0 / 3, t0 % 3, 0);
             load_x(xa[1], p0, t0 / 3, t0 % 3, 1);
@@ -1276,31 +1301,43 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
     // prologue: halo of slab 0, weight stages 0 and 1
     dma_patch(0, 0);
     dma_stage(0, 0, 0);
-    dma_stage(1, 0, 2);
+    dma_stage(1, 0, TPS);
     CY_WAIT_VM(WPS);
     __builtin_amdgcn_s_barrier();
 #pragma unroll 1
     for (int cp = 0; cp < pairs; ++cp) {
         const bool more = cp + 1 < pairs;
 #pragma unroll
-        for (int st = 0; st < 9; ++st) {
-            // stage g = 9*cp + st uses ring slot st % 3; request the weights of stage g+2 and the halo buffers just freed
-            const bool has_w = st <= 6 || more;
-            if (st <= 6) dma_stage((st + 2) % 3, 2 * cp, 2 * (st + 2));
-            else if (more) dma_stage((st + 2) % 3, 2 * cp + 2, 2 * (st + 2 - 9));
-            if (st == 0) dma_patch(1, 2 * cp + 1);                        // odd slab of this pair (first read in stage 4)
-            if (st == 5 && more) dma_patch(0, 2 * cp + 2);                // even slab of the next pair
+        for (int st = 0; st < NST; ++st) {
+            // stage g = NST*cp + st uses ring slot st % 3; request the weights of stage g+2 and the halo buffers just freed
+            const bool has_w = st + 2 < NST || more;
+            if (st + 2 < NST) dma_stage((st + 2) % 3, 2 * cp, TPS * (st + 2));
+            else if (more) dma_stage((st + 2) % 3, 2 * cp + 2, TPS * (st + 2 - NST));
+            // halo: odd slab of this pair (first read in stage NST/2, rounded up) and even slab of the next pair (its buffer
+            // is free once the stage holding tap 8 is done)
+            constexpr int ST_EVEN = TPS == 2 ? 5 : 3;
+            if (st == 0) dma_patch(1, 2 * cp + 1);
+            if (st == ST_EVEN && more) dma_patch(0, 2 * cp + 2);
             stage_compute(st);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             // the weights of stage g+1 (requested first thing in stage g-1) must have landed; younger requests may fly on
-            if (st == 0 || st == 1) { CY_WAIT_VM(WPS + PROUNDS); }
-            else if (st == 5 || st == 6) { if (more) { CY_WAIT_VM(WPS + PROUNDS); } else { CY_WAIT_VM(WPS); } }
-            else if (has_w) { CY_WAIT_VM(WPS); }
-            else { CY_WAIT_VM(0); }
+            if constexpr (TPS == 2) {
+                if (st == 0 || st == 1) { CY_WAIT_VM(WPS + PROUNDS); }
+                else if (st == 5 || st == 6) { if (more) { CY_WAIT_VM(WPS + PROUNDS); } else { CY_WAIT_VM(WPS); } }
+                else if (has_w) { CY_WAIT_VM(WPS); }
+                else { CY_WAIT_VM(0); }
+            } else {
+                // a halo patch requested in stage 0 / 3 is first read in stage 3 / (next pair's) 0: it may stay in flight for two stages
+                if (st == 0 || st == 1) { CY_WAIT_VM(WPS + PROUNDS); }
+                else if (st == 3) { if (more) { CY_WAIT_VM(WPS + PROUNDS); } else { CY_WAIT_VM(WPS); } }
+                else if (st == 4) { if (more) { CY_WAIT_VM(WPS + PROUNDS); } else { CY_WAIT_VM(0); } }
+                else if (has_w) { CY_WAIT_VM(WPS); }
+                else { CY_WAIT_VM(0); }
+            }
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            if (TAIL) mma(wb[1], xa[1], WN == 2 ? 1 : 0);    // operands are in registers: overlaps the next stage's DMA issue / first reads
+            if (TAIL) mma(wb[TPS == 3 ? 0 : 1], xa[1], WN == 2 ? 1 : 0);    // operands are in registers: overlaps the next stage's DMA issue / first reads
         }
     }
 
@@ -1364,21 +1401,21 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
     }
 }
 
-template <int WN, bool DUAL = false>
+template <int WN, bool DUAL = false, int TPS = 2>
 static hipError_t launch_wide(const ConvArgs& a, hipStream_t s) {
     constexpr int PR = 18 * (DUAL ? 36 : 34), NPC = (PR + 15) / 16, PROUNDS = (NPC + 7) / 8, BN = 64 * WN;
-    const size_t lds = 2 * PROUNDS * 8 * 1024 + 3 * 2 * BN * 64;
+    const size_t lds = 2 * PROUNDS * 8 * 1024 + 3 * TPS * BN * 64;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wide_kernel<false, WN, DUAL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wide_kernel<true, WN, DUAL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wide_kernel<false, WN, DUAL, TPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wide_kernel<true, WN, DUAL, TPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const int bx = DUAL ? (a.B + 1) / 2 : a.B * ((a.Wi + 31) / 32);
     const int blocks = bx * ((a.Hi + 15) / 16) * ((pad64(a.Cout) + BN - 1) / BN);
     static const int tail = getenv("CY_WIDE_TAIL") ? atoi(getenv("CY_WIDE_TAIL")) : 1;
-    if (tail) hipLaunchKernelGGL((conv3x3_wide_kernel<true, WN, DUAL>), dim3(blocks), dim3(512), lds, s, a);
-    else hipLaunchKernelGGL((conv3x3_wide_kernel<false, WN, DUAL>), dim3(blocks), dim3(512), lds, s, a);
+    if (tail) hipLaunchKernelGGL((conv3x3_wide_kernel<true, WN, DUAL, TPS>), dim3(blocks), dim3(512), lds, s, a);
+    else hipLaunchKernelGGL((conv3x3_wide_kernel<false, WN, DUAL, TPS>), dim3(blocks), dim3(512), lds, s, a);
     return hipGetLastError();
 }
 
@@ -1714,7 +1751,10 @@ hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s) {
             return v == 1 ? launch_halo<2, 3, 1>(b2, s) : launch_halo<2, 2>(b2, s);
         }
         case CONV_GENERIC_BIG: return launch_t<f16, 4, 2, 4, 3>(a, s);
-        case CONV_WIDE_128: return launch_wide<2>(a, s);
+        case CONV_WIDE_128: {
+            static const int tps = getenv("CY_WIDE_TPS") ? atoi(getenv("CY_WIDE_TPS")) : 2;
+            return tps == 3 ? launch_wide<2, false, 3>(a, s) : launch_wide<2>(a, s);
+        }
         case CONV_WIDE_64: return launch_wide<1>(a, s);
         case CONV_WIDE_DUAL: return launch_wide<2, true>(a, s);
         case CONV_DIRECT_256: {
