@@ -1688,8 +1688,14 @@ const char* conv_variant_name(int v) { return v >= 0 && v < CONV_NUM_VARIANTS ? 
 
 static bool s2_direct() { static const int v = getenv("CY_S2_DIRECT") ? atoi(getenv("CY_S2_DIRECT")) : 1; return v != 0; }
 
+// CY_BATCH_INVARIANT=1: every batch-size threshold below (and the stem fusion) is evaluated as if the batch held >= 256
+// tiles, so a layer always runs the SAME kernel and a tile's fp16 results do not depend on how many tiles share its batch:
+// catalogs are then identical for any world size / batch split, at the cost of big-batch kernels on small batches.
+bool batch_invariant() { const char* e = getenv("CY_BATCH_INVARIANT"); return e && atoi(e) != 0; }
+
 int conv_variant(Precision p, const ConvArgs& a) {
     const bool narrow = pad64(a.Cout) <= 64;
+    const long Bv = batch_invariant() && a.B < 256 ? 256 : a.B;     // the batch size the thresholds see
     // 3x3 stride-1 layers (fp16 context; the fp32 parity context keeps the generic kernel): halo-reuse kernels.
     //   Cout <= 64  : ping-pong kernel with 64-channel tiles (256 px x 64 ch per workgroup)
     //   Cout >= 128 : 8x16-pixel patches x 128 channels, two workgroups per CU
@@ -1702,7 +1708,7 @@ int conv_variant(Precision p, const ConvArgs& a) {
         static const int wide64 = getenv("CY_WIDE64") ? atoi(getenv("CY_WIDE64")) : 1;
         // 64-channel variant of the wide kernel for the box-head convs with deep inputs, when it fills the chip
         if (narrow && wide64 && a.wgt32 && a.Cin >= 128 && a.Wi % 32 == 0 && force == 0 &&
-            (long)a.B * ((a.Hi + 15) / 16) * (a.Wi / 32) >= 256)
+            Bv * ((a.Hi + 15) / 16) * (a.Wi / 32) >= 256)
             return CONV_WIDE_64;
         if (narrow && a.Cin == 64 && force != 8) return force == 9 ? CONV_GENERIC_64 : CONV_C64_PERSIST;
         if (narrow) return force == 9 ? CONV_GENERIC_64 : CONV_PP_64;
@@ -1715,7 +1721,7 @@ int conv_variant(Precision p, const ConvArgs& a) {
         // two 16-px-wide images side by side: +8 % over the two-tap halo kernel once it still fills the chip (half as many
         // workgroups), slower below that
         if (wide && dual && a.wgt32 && a.Wi <= 16 && a.Wi >= 14 &&
-            (long)((a.B + 1) / 2) * ((a.Hi + 15) / 16) * ((pad64(a.Cout) + 127) / 128) >= (dual > 1 ? 1 : 224))
+            ((Bv + 1) / 2) * ((a.Hi + 15) / 16) * ((pad64(a.Cout) + 127) / 128) >= (dual > 1 ? 1 : 224))
             return CONV_WIDE_DUAL;
         return CONV_HALO8_128;
     }
@@ -1728,12 +1734,12 @@ int conv_variant(Precision p, const ConvArgs& a) {
         const long min_blocks = e ? atol(e) : 256;
         static const int bn_force = getenv("CY_DIRECT_BN") ? atoi(getenv("CY_DIRECT_BN")) : 0;      // tuning knob
         const int bn = bn_force == 128 && a.k == 1 ? 128 : (pad64(a.Cout) >= 256 ? 256 : 128);
-        const long blocks = (((long)a.B * a.Ho * a.Wo + 255) / 256) * ((pad64(a.Cout) + bn - 1) / bn);
+        const long blocks = ((Bv * a.Ho * a.Wo + 255) / 256) * ((pad64(a.Cout) + bn - 1) / bn);
         if (min_blocks >= 0 && blocks >= min_blocks) return bn == 256 ? CONV_DIRECT_256 : CONV_DIRECT_128;
     }
     // 1x1 and strided convs with enough 256-pixel tiles to fill the chip: deeper-pipelined 256x128 tile
     static const int big = getenv("CY_BIG") ? atoi(getenv("CY_BIG")) : 1;
-    const long M = (long)a.B * a.Ho * a.Wo;
+    const long M = Bv * a.Ho * a.Wo;
     if (p == PREC_F16 && big && (M / 256) * ((pad64(a.Cout) + 127) / 128) >= big * 256) return CONV_GENERIC_BIG;
     return CONV_GENERIC_128;
 }

@@ -69,6 +69,7 @@ void debug_read_stamps(unsigned long long* out8, bool reset);   // developer dia
 hipError_t launch_stem(Precision p, const StemArgs& a, hipStream_t s);
 hipError_t launch_stem_down(const StemDownArgs& a, hipStream_t s);
 long stem_down_blocks(const StemDownArgs& a);
+bool batch_invariant();                                            // CY_BATCH_INVARIANT=1 (conv_igemm.hip)
 void pack_stem_weights2(const float* W, int cout, void* dst);     // 64*64 fp16, k = tap*4 + c (taps 0..7), 32 + c (tap 8)
 hipError_t launch_pool5(Precision p, const PoolArgs& a, hipStream_t s);
 

@@ -508,7 +508,7 @@ static int forward_on(cy_ctx* c, const void* d_netin, int B, int H, int W, float
             a.wpk2 = reinterpret_cast<const char*>(c->dconv[o.conv].w) + 64 * 32 * 2; a.bias0 = c->dconv[o.conv].bias;
             a.wgt32 = c->dconv[n.conv].w32; a.wgt32_bytes = (uint32_t)c->dconv[n.conv].w32bytes; a.bias1 = c->dconv[n.conv].bias;
             a.out = tp(n.out); a.out_ct = to.C; a.out_coff = n.out_coff;
-            if (ti.C == 4 && (fuse_env > 1 || stem_down_blocks(a) >= 256)) {
+            if (ti.C == 4 && (fuse_env > 1 || batch_invariant() || stem_down_blocks(a) >= 256)) {
                 HIPCHK(c, launch_stem_down(a, s));
                 prof_done(CONV_NUM_VARIANTS, 2.0 * Bn * a.H1 * a.W1 * 64 * 27.0 + 2.0 * Bn * a.Ho * a.Wo * 128.0 * 64 * 9);
                 *fused = true; c->stem_fused_last = true;

@@ -120,3 +120,22 @@ def test_other_scales_fp32(scale, nc):
         err = float((pred.cpu() - raw).abs().max())
         assert err <= tol * max(1.0, float(raw.abs().max())), (scale, prec, err)
         det.close()
+
+
+def test_batch_invariant_mode_is_bit_exact(monkeypatch):
+    """CY_BATCH_INVARIANT=1 (fp16 context): every layer takes the kernel a 256-tile batch would take, whatever the batch, so
+    a tile's head output is bit-identical alone, in a batch of 4, and through the split (two-stream) forward - the
+    property that makes catalogs independent of the world size."""
+    monkeypatch.setenv("CY_BATCH_INVARIANT", "1")
+    det = detector("fp16")
+    base = _tile("big512", 256, 256)
+    imgs = [base, base[::-1].copy(), base[:, ::-1].copy(), base[::-1, ::-1].copy()]
+    x, raw, _ = _oracle_forward(imgs, 256)
+    xin = netin_from_chw(x, det.dtype)
+    p4 = det.forward(xin).cpu()
+    assert float((p4 - raw).abs().max()) <= 6e-2 * max(1.0, float(raw.abs().max()))
+    for i in range(4):
+        p1 = det.forward(xin[i:i + 1].contiguous()).cpu()
+        assert torch.equal(p1[0], p4[i]), "tile %d differs between batch 1 and batch 4" % i
+    p3 = det.forward(xin[1:4].contiguous()).cpu()
+    assert torch.equal(p3, p4[1:4])

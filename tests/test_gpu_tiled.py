@@ -178,3 +178,34 @@ def test_split_forward_gives_the_same_detections(monkeypatch):
         np.testing.assert_allclose(a[1], b[1], atol=5e-3)
         np.testing.assert_array_equal(a[2], b[2])
         np.testing.assert_allclose(a[0], b[0], atol=0.5)
+
+
+def test_batch_invariant_detections_do_not_depend_on_batching(monkeypatch):
+    """With CY_BATCH_INVARIANT=1 the per-tile detections are the same bits whether the tiles go through cy_detect_tiles
+    one by one, all together, or as two half-batches on two streams."""
+    from caesar_yolo_amd.model import YOLO
+    from caesar_yolo_amd import preprocessing as PP
+    monkeypatch.setenv("CY_BATCH_INVARIANT", "1")
+    img = np.load(os.path.join(ROOT, "tests/golden/mosaic_c.npz"))["img"].astype(np.float32)
+    model = YOLO(seeded_weights()[0], precision="fp16", max_batch=8, max_imgsz=256, device=0)
+    mosaic = model.engine().mosaic_to_device(img)
+    cfg = PP.DataPreprocessor([PP.ZScaleTransformer([0.25] * 3), PP.MinMaxNormalizer(0, 255)]).program()
+    coords = [(0, 256, 0, 256), (256, 512, 0, 256), (128, 384, 128, 384), (600, 856, 400, 656), (300, 556, 200, 456)]
+    kw = dict(imgsz=256, conf=0.3, iou=IOU, merge_overlap_iou_thr_soft=SOFT, merge_overlap_iou_thr_hard=HARD)
+
+    def run(groups, mode):
+        monkeypatch.setenv("CY_DUAL_FORWARD", mode)
+        out = []
+        for g in groups:
+            out += model.predict_tiles(mosaic, g, cfg, **kw)
+        return [None if r is None else np.concatenate([r.boxes.xyxy.cpu().numpy(), r.boxes.conf.cpu().numpy()[:, None],
+                                                       r.boxes.cls.cpu().numpy()[:, None]], 1) for r in out]
+    together = run([coords], "0")
+    alone = run([[c] for c in coords], "0")
+    split = run([coords], "2")
+    assert sum(len(t) for t in together if t is not None) >= 8
+    for a, b, c in zip(together, alone, split):
+        assert (a is None) == (b is None) == (c is None)
+        if a is not None:
+            np.testing.assert_array_equal(a, b)
+            np.testing.assert_array_equal(a, c)
