@@ -1688,10 +1688,13 @@ const char* conv_variant_name(int v) { return v >= 0 && v < CONV_NUM_VARIANTS ? 
 
 static bool s2_direct() { static const int v = getenv("CY_S2_DIRECT") ? atoi(getenv("CY_S2_DIRECT")) : 1; return v != 0; }
 
-// CY_BATCH_INVARIANT=1: every batch-size threshold below (and the stem fusion) is evaluated as if the batch held >= 256
-// tiles, so a layer always runs the SAME kernel and a tile's fp16 results do not depend on how many tiles share its batch:
-// catalogs are then identical for any world size / batch split, at the cost of big-batch kernels on small batches.
-bool batch_invariant() { const char* e = getenv("CY_BATCH_INVARIANT"); return e && atoi(e) != 0; }
+// Batch-invariant kernel selection (default; CY_BATCH_INVARIANT=0 turns it off): every batch-size threshold below (and the
+// stem fusion) is evaluated as if the batch held >= 256 tiles, so a layer always runs the SAME kernel and a tile's fp16
+// results do not depend on how many tiles share its batch: catalogs are identical for any world size / batch split, as the
+// reference's are for any MPI size.  Price: big-batch kernels on small batches (1 % of the 16k-mosaic rate; a single
+// image runs kernels tuned for 256).  With 0 the thresholds see the real batch: fastest per batch size, last-bit differences
+// between batch sizes.
+bool batch_invariant() { const char* e = getenv("CY_BATCH_INVARIANT"); return !e || atoi(e) != 0; }
 
 int conv_variant(Precision p, const ConvArgs& a) {
     const bool narrow = pad64(a.Cout) <= 64;

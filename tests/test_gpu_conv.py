@@ -44,9 +44,12 @@ CASES = [  # B, H, W, Cin, Cout, k, s, act, residual
 ]
 
 
-@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+# fp16 twice: with the default batch-invariant kernel selection (thresholds see a 256-tile batch) and with the selection
+# that sees the real (small) batch of the case: between them every kernel variant runs
+@pytest.mark.parametrize("prec,inv", [("fp32", "1"), ("fp16", "1"), ("fp16", "0")])
 @pytest.mark.parametrize("case", CASES)
-def test_conv_bn_silu(prec, case, monkeypatch):
+def test_conv_bn_silu(prec, inv, case, monkeypatch):
+    monkeypatch.setenv("CY_BATCH_INVARIANT", inv)
     monkeypatch.setenv("CY_WIDE_DUAL", "2")       # the dual-image kernel normally waits for benchmark-sized batches: force it here
     B, H, W, Cin, Cout, k, s, act, use_res = case
     det = detector(prec)
@@ -94,6 +97,7 @@ def test_conv_random_geometry_fp16(seed, monkeypatch):
     use_res = bool(rng.integers(0, 2))
     if seed % 2:
         monkeypatch.setenv("CY_DIRECT_MIN_BLOCKS", "1")
+    monkeypatch.setenv("CY_BATCH_INVARIANT", str((seed // 2) % 2))
     det = detector("fp16")
     g = torch.Generator().manual_seed(seed)
     x = (torch.randn((B, Cin, H, Wd), generator=g)).half().float()

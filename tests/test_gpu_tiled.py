@@ -181,11 +181,11 @@ def test_split_forward_gives_the_same_detections(monkeypatch):
 
 
 def test_batch_invariant_detections_do_not_depend_on_batching(monkeypatch):
-    """With CY_BATCH_INVARIANT=1 the per-tile detections are the same bits whether the tiles go through cy_detect_tiles
+    """With the default (batch-invariant) kernel selection the per-tile detections are the same bits whether the tiles go through cy_detect_tiles
     one by one, all together, or as two half-batches on two streams."""
     from caesar_yolo_amd.model import YOLO
     from caesar_yolo_amd import preprocessing as PP
-    monkeypatch.setenv("CY_BATCH_INVARIANT", "1")
+    monkeypatch.delenv("CY_BATCH_INVARIANT", raising=False)          # the default selection is the invariant one
     img = np.load(os.path.join(ROOT, "tests/golden/mosaic_c.npz"))["img"].astype(np.float32)
     model = YOLO(seeded_weights()[0], precision="fp16", max_batch=8, max_imgsz=256, device=0)
     mosaic = model.engine().mosaic_to_device(img)
