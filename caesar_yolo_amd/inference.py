@@ -238,10 +238,10 @@ def merge_records(det, dtile, grid):
     T = tiles.shape[0]
     lib = L.load()
     ip, fp, dp = C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_double)
-    rec = np.zeros((n, 8), np.float64)
+    rec = np.empty((n, 8), np.float64)                  # every row is written by cy_make_tile_records
     L.check(lib.cy_make_tile_records(det.ctypes.data_as(fp), dtile.ctypes.data_as(ip), n, tiles.ctypes.data_as(ip), T,
                                      rec.ctypes.data_as(dp)))
-    out = np.zeros((n, 8), np.float64)
+    out = np.empty((n, 8), np.float64)                  # rows [0, m) are written, the rest is dropped
     m = L.check(lib.cy_merge_edge_sources(rec.ctypes.data_as(dp), n, tiles.ctypes.data_as(ip), T, out.ctypes.data_as(dp)))
     return out[:m]
 
