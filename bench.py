@@ -1,21 +1,29 @@
 #!/usr/bin/env python
 """Benchmark of the tiled-YOLO detect path on MI355X (driver contract: one JSON line on stdout from rank 0).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config s16k|c5]
 
-Workload = BASELINE.json configs[2]/[3]: a seeded synthetic 16384x16384 single-channel mosaic (caesar_yolo_amd/synth.py,
-"S16k"), 512x512 tiles at step 0.8 -> 1600 tiles (1521 full, 39+39 ragged, 1 corner), --preprocessing zscale(0.25) +
-minmax(0,255), imgsz 512, conf 0.7, NMS IoU 0.5, merge thresholds 0.3/0.8, yolov8l nc=5 with seeded random-init weights.
+With N > 1 and no WORLD_SIZE in the environment this process only spawns the ranks (`python -m torch.distributed.run
+--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>`, one process per GPU over RCCL; it replaces
+`mpirun -np N ... run.py` of the reference, test/run_inference_parallel.sh:47-52) BEFORE touching the GPU, relays rank 0's JSON
+line and exits with the children's status.  Launched under torch.distributed.run it is one of those ranks.
+
+Workload "s16k" = BASELINE.json configs[2]/[3]: a seeded synthetic 16384x16384 single-channel mosaic (caesar_yolo_amd/synth.py),
+512x512 tiles at step 0.8 -> 1600 tiles (1521 full, 39+39 ragged, 1 corner), --preprocessing zscale(0.25) + minmax(0,255),
+imgsz 512, conf 0.7, NMS IoU 0.5, merge thresholds 0.3/0.8, yolov8l nc=5 with seeded random-init weights.
+Workload "c5" = BASELINE.json configs[4] at one-GPU size: the S32k recipe at 8192x8192, --chan3_preproc 3-channel preprocessing,
+640x640 tiles at step 0.8 -> 256 tiles, imgsz 640 (reported under its own metric name; the default and the headline is s16k).
+
 One STEP = one full pass over the mosaic's tile grid: every tile of this rank's share through crop -> preprocessing ->
 letterbox/pack -> YOLOv8l forward -> decode/NMS -> IoU merge (all on device, fp16 operands / fp32 accumulate), then ONE
-all-gather of detection records and the cross-tile merge into the final catalog in host memory.  The mosaic is resident in
-HBM before the timed region.  value = tiles processed by all ranks / wall time (max over ranks); total work is fixed as
-N grows ("strong").
+all-gather of detection records and the cross-tile merge into the final catalog in host memory.  The rank's part of the mosaic
+is resident in HBM before the timed region (FITS read + H2D + byte swap are reported separately as `ms_ingest`).
+value = tiles processed by all ranks / wall time (max over ranks); total work is fixed as N grows ("strong").
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -23,26 +31,92 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP16_DENSE_TFLOPS = 2500.0      # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md, "~2.5 PF dense")
-FLOP_PER_TILE_512 = 105.488e9        # algorithmic conv FLOPs per 512x512 tile, yolov8l nc=5
+WORKLOADS = {
+    # name: mosaic edge, seed, tile, step, imgsz, algorithmic conv FLOPs per full tile (yolov8l nc=5)
+    "s16k": dict(size=16384, seed=20260104, tile=512, step=0.8, imgsz=512, flop=105.488e9, batch=256,
+                 metric="512x512 tiles/sec over 16k x 16k FITS", pre="zscale+minmax"),
+    "c5": dict(size=8192, seed=20260105, tile=640, step=0.8, imgsz=640, flop=164.825e9, batch=128,
+               metric="640x640 chan3 tiles/sec over 8k x 8k FITS (config 5 at one-GPU size)", pre="chan3+minmax"),
+}
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(mosaic_host, grid, names_w, budget_s=22.0, max_tiles=32, budget_8t_s=8.0):
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", choices=sorted(WORKLOADS), default="s16k")
+    ap.add_argument("--size", type=int, default=0, help="mosaic edge (default: the workload's)")
+    ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not record per-launch hipEvents in the timed region")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="ranks only rendezvous, partition the grid and run the (empty) all-gather on CPU tensors: exercises the "
+                         "launch path on a box without GPUs (tests/test_bench_spawn.py)")
+    ap.add_argument("--fail-rank", type=int, default=-1, help=argparse.SUPPRESS)     # test hook: that rank exits 3
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------ launcher
+def spawn_ranks(args, argv):
+    """Parent of an N-rank run: never initialises the GPU.  Returns the exit status."""
+    import socket
+    import __graft_entry__ as ge
+    ge.build(load=False)                                   # compile once, before N ranks race for it
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    log("bench: spawning %d ranks: %s" % (args.gpus, " ".join(cmd)))
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout:
+        ln = ln.rstrip("\n")
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        elif ln:
+            log(ln)
+    rc = p.wait()
+    if rc != 0:
+        log("bench: a rank failed (launcher exit status %d)" % rc)
+        return rc if 0 < rc < 256 else 1
+    if line is None:
+        log("bench: the ranks printed no result line")
+        return 1
+    if json.loads(line).get("n_gpus") != args.gpus:
+        log("bench: result line reports n_gpus=%r, %d were asked for" % (json.loads(line).get("n_gpus"), args.gpus))
+        return 1
+    print(line, flush=True)
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def cpu_baseline(mosaic_host, grid, names_w, wl, budget_s=24.0, max_tiles=48):
     """The CPU oracle (restated reference path: numpy preprocessing + torch-CPU fp32 YOLOv8l + NMS + IoU merge),
-    sequential, batch 1 like caesar_yolo/inference.py:611-622, on a bounded sample of the same tiles."""
+    sequential, batch 1 like caesar_yolo/inference.py:611-622, on a bounded sample of the same tiles, at several thread
+    counts (the best is reported; `cores` = the threads it used)."""
     import numpy as np
     import torch
+    from caesar_yolo_amd import pipelines as CP
     from oracle import preprocessing_ref as P
     from oracle import yolov8_ref as Y
     from oracle import postproc_ref as R
     scale, names, wd = names_w
-    cores = torch.get_num_threads()
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 8
     om = Y.OracleYOLO(wd, names, scale)
-    dp = P.build_pipeline([("zscale", dict(contrasts=[0.25] * 3)), ("minmax", dict(norm_min=0, norm_max=255))])
-    full = [i for i, t in enumerate(grid) if t[1] - t[0] == 512 and t[3] - t[2] == 512]
+    dp = P.build_pipeline(CP.SPECS[wl["pre"]])
+    ts = wl["tile"]
+    full = [i for i, t in enumerate(grid) if t[1] - t[0] == ts and t[3] - t[2] == ts]
     sample = full[len(full) // 3:][:max_tiles]
 
     def run(tids, budget):
@@ -51,33 +125,32 @@ def cpu_baseline(mosaic_host, grid, names_w, budget_s=22.0, max_tiles=32, budget
             x0, x1, y0, y1 = grid[tid]
             tile = np.array(mosaic_host[y0:y1, x0:x1], dtype=np.float32)
             tile[~np.isfinite(tile)] = 0
-            img = dp(P.to_cube(tile))
+            img = dp(P.to_cube(tile)) if np.any(tile) else None
             if img is not None and not P.rows_constant(img):
-                det, _, _, _ = om.predict_raw(img, 512, 0.7, 0.5)
+                det, _, _, _ = om.predict_raw(img, wl["imgsz"], 0.7, 0.5)
                 R.process_detections(det[:, :4].numpy(), det[:, 4].numpy(), det[:, 5].numpy(), 0.7, 0.3, 0.8)
             done += 1
             if time.time() - t0 > budget:
                 break
         return done, time.time() - t0
     run(sample[:1], 60.0)                                  # untimed first tile (thread pool / allocator warm-up)
+    counts = [n for n in (8, 16, 32, 64) if n <= max(avail, 8)]
     runs = []
-    for nthr, budget in ((cores, budget_s * 0.5), (8, budget_8t_s + budget_s * 0.5)):      # all cores, and 8 threads
-        if nthr > cores or any(r["threads"] == nthr for r in runs):
-            continue
+    for nthr in counts:
         torch.set_num_threads(nthr)
-        done, dt = run(sample, budget)
+        done, dt = run(sample, budget_s / len(counts))
         runs.append({"threads": nthr, "tiles_per_s": done / dt, "tiles": done, "seconds": dt})
-    torch.set_num_threads(cores)
-    best = max(runs, key=lambda r: r["tiles_per_s"])        # the better of the two is the baseline (more threads is not faster here)
+    best = max(runs, key=lambda r: r["tiles_per_s"])
     return {"value": best["tiles_per_s"], "unit": "tiles/s", "cores": best["threads"], "kind": "port",
-            "sample": "%d full 512x512 tiles of the S16k grid (tids %d..), sequential batch 1, zscale+minmax + torch-CPU fp32 "
-                      "yolov8l + NMS + IoU merge, %.1f s with %d torch threads" % (best["tiles"], sample[0], best["seconds"], best["threads"]),
+            "host_cores_available": avail,
+            "sample": "%d full %dx%d tiles of the grid (tids %d..), sequential batch 1, %s + torch-CPU fp32 yolov8l + NMS + IoU "
+                      "merge, %.1f s with %d torch threads" % (best["tiles"], ts, ts, sample[0], wl["pre"], best["seconds"], best["threads"]),
             "runs": runs}
 
 
 def pmc_traffic(kernel_label):
     """HBM bytes per launch of the dominant kernel from the tracked rocprofv3 PMC passes (profiles/*_hbm_traffic.json,
-    collected by tools/collect_profiles.sh on this same command line); None if no profile has been recorded."""
+    collected by tools/collect_profiles.sh on this same command line) -> (bytes or None, file it came from)."""
     import glob
 
     def family(n):
@@ -94,7 +167,7 @@ def pmc_traffic(kernel_label):
                 return "conv_igemm_kernel<4,2,4,3>"
             return "conv_igemm_kernel<2,2,4>" if ("<2,2,4>" in n or "Li2ELi2ELi4E" in n) else "conv_igemm_kernel<4,1,2>"
         return None
-    want, best = family(kernel_label), None
+    want, best, src = family(kernel_label), None, None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json"))):
         try:
             t = json.load(open(f))
@@ -102,34 +175,57 @@ def pmc_traffic(kernel_label):
             continue
         for name, v in t.items():
             if want and family(name) == want:
-                best = v["hbm_bytes_per_launch"]
-    return best
+                best, src = v["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
+    return best, src
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--size", type=int, default=16384, help="mosaic edge (default: the 16k config)")
-    ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-profile", action="store_true", help="do not record per-launch hipEvents in the timed region")
-    args = ap.parse_args()
-
-    import numpy as np
+# ------------------------------------------------------------------------------------------------ one rank
+def dry_run(args, wl, rank, world):
+    """No GPU: rendezvous over gloo, the deterministic partition, one all-gather of empty records on CPU tensors."""
     import torch
     import torch.distributed as dist
-    import __graft_entry__ as ge
+    from caesar_yolo_amd import utils
+    from caesar_yolo_amd.inference import partition_tiles
+    if world > 1:
+        dist.init_process_group("gloo")
+    if rank == args.fail_rank:
+        sys.exit(3)
+    size = args.size or wl["size"]
+    grid = utils.generate_tiles(0, size - 1, 0, size - 1, wl["tile"], wl["tile"], wl["step"], wl["step"])
+    parts = partition_tiles(grid, wl["imgsz"], world, args.batch or wl["batch"])
+    mine = torch.tensor([float(sum(len(t) for _, t in parts[rank]))])
+    counts = [mine.clone() for _ in range(world)]
+    if world > 1:
+        dist.all_gather(counts, mine)
+    if rank == 0:
+        print(json.dumps({"metric": wl["metric"], "value": 0.0, "unit": "tiles/s", "dry_run": True,
+                          "n_gpus": dist.get_world_size() if world > 1 else 1, "steps": 0, "warmup": 0,
+                          "tiles_per_rank": [int(c.item()) for c in counts], "tiles": len(grid)}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_rank(args):
+    wl = WORKLOADS[args.config]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        log("note: WORLD_SIZE=%d, --gpus=%d; using WORLD_SIZE" % (world, args.gpus))
+        log("bench: WORLD_SIZE=%d but --gpus=%d: refusing to report a line for the wrong rank count" % (world, args.gpus))
+        return 2
+    if args.dry_run:
+        dry_run(args, wl, rank, world)
+        return 0
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
     ndev = torch.cuda.device_count()
     backend = os.environ.get("CY_BENCH_BACKEND", "nccl")     # "gloo": rehearsal of the N>1 path on fewer GPUs than ranks
     if local >= ndev and backend == "nccl":
-        raise SystemExit("rank %d has no GPU (found %d); one process per GPU is required" % (rank, ndev))
+        log("rank %d has no GPU (found %d); one process per GPU is required" % (rank, ndev))
+        return 2
     local = local % max(ndev, 1)
     torch.cuda.set_device(local)
     if world > 1:
@@ -144,25 +240,40 @@ def main():
         dist.barrier()
 
     from caesar_yolo_amd import synth, utils, weights as W
-    from caesar_yolo_amd import preprocessing as PP
     from caesar_yolo_amd.model import YOLO
-    from caesar_yolo_amd.inference import TileEngine
+    from caesar_yolo_amd.inference import TileEngine, MosaicSource
+    from caesar_yolo_amd import pipelines as CP
 
+    size = args.size or wl["size"]
+    batch = args.batch or wl["batch"]
     t_setup = time.time()
-    model = YOLO("seeded:l:5", precision="fp16", max_batch=args.batch, max_imgsz=512, device=local) if rank == 0 else None
-    if world > 1:
-        dist.barrier()                       # rank 0 wrote the seeded weight file; the others reuse it
-    if model is None:
-        model = YOLO("seeded:l:5", precision="fp16", max_batch=args.batch, max_imgsz=512, device=local)
-    det = model.engine(local)
-    mosaic_host = synth.make_mosaic(args.size, seed=20260104)
-    mosaic = det.mosaic_to_device(mosaic_host)          # resident before the timed region
-    grid = utils.generate_tiles(0, args.size - 1, 0, args.size - 1, 512, 512, 0.8, 0.8)
-    cfg = PP.DataPreprocessor([PP.ZScaleTransformer([0.25] * 3), PP.MinMaxNormalizer(0, 255)]).program()
-    eng = TileEngine(det, mosaic, grid, cfg, 512, 0.7, 0.5, 0.3, 0.8, rank, world, args.batch)
-    torch.cuda.synchronize()
+    # rank 0 writes the seeded weight file and the synthetic FITS; the others reuse both
+    import tempfile
+    fits_path = os.path.join(tempfile.gettempdir(), "cy_bench_%s_%d_%d.fits" % (args.config, size, os.getuid()))
+    mosaic_host = None
+    model = None
     if rank == 0:
-        log("setup %.1f s: %d tiles, %d ranks, %d tiles on rank 0" % (time.time() - t_setup, len(grid), world, eng.n_my))
+        model = YOLO("seeded:l:5", precision="fp16", max_batch=batch, max_imgsz=wl["imgsz"], device=local)
+        mosaic_host = synth.make_mosaic(size, seed=wl["seed"])
+        utils.write_fits_image(fits_path, mosaic_host, synth.FITS_CARDS)
+    if world > 1:
+        dist.barrier()
+    if model is None:
+        model = YOLO("seeded:l:5", precision="fp16", max_batch=batch, max_imgsz=wl["imgsz"], device=local)
+    det = model.engine(local)
+    grid = utils.generate_tiles(0, size - 1, 0, size - 1, wl["tile"], wl["tile"], wl["step"], wl["step"])
+    cfg = CP.device_pipeline(wl["pre"]).program()
+    # ingest, timed: FITS header + memory map -> this rank's regions -> H2D -> byte swap / non-finite -> 0 on device
+    torch.cuda.synchronize()
+    t_in = time.time()
+    data, _hdr = utils.read_fits_image(fits_path)
+    src = MosaicSource(data, big_endian=True)
+    eng = TileEngine(det, src, grid, cfg, wl["imgsz"], 0.7, 0.5, 0.3, 0.8, rank, world, batch)
+    torch.cuda.synchronize()
+    ms_ingest = 1000.0 * (time.time() - t_in)
+    if rank == 0:
+        log("setup %.1f s: %d tiles, %d ranks, %d tiles on rank 0, ingest %.1f ms (%.1f MB on device)" % (
+            time.time() - t_setup, len(grid), world, eng.n_my, ms_ingest, src.bytes_uploaded / 1e6))
 
     tsplit = {"local": 0.0, "gather": 0.0, "merge": 0.0}
 
@@ -174,12 +285,12 @@ def main():
         eng.gather()
         torch.cuda.synchronize()
         t2 = time.time()
-        src = stats = None
+        cat = stats = None
         if rank == 0:
-            src, stats = eng.merged_records()         # final catalog records in host memory (D2H synchronises)
+            cat, stats = eng.merged_records()         # final catalog records in host memory (D2H synchronises)
         t3 = time.time()
         tsplit["local"] += t1 - t0; tsplit["gather"] += t2 - t1; tsplit["merge"] += t3 - t2
-        return src, stats
+        return cat, stats
 
     for _ in range(args.warmup):
         step()
@@ -192,42 +303,66 @@ def main():
     torch.cuda.synchronize()
     t0 = time.time()
     for _ in range(args.steps):
-        src, stats = step()
+        cat, stats = step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.time() - t0
+    per_rank = None
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        cpu = dist.get_backend() != "nccl"
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if cpu else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        mine = torch.tensor([tsplit["local"], tsplit["gather"], ms_ingest, float(eng.n_my), float(src.bytes_uploaded)],
+                            dtype=torch.float64, device="cpu" if cpu else "cuda")
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [[float(v) for v in t.cpu()] for t in allr]
     prof = det.profile_summary() if not args.no_profile else None
     det.profile(False)
 
     if rank == 0:
         ntiles = len(grid)
         value = ntiles * args.steps / dt
+        n_gpus = dist.get_world_size() if world > 1 else 1        # the ranks the communicator actually has
+        ms_step = 1000.0 * dt / args.steps
+        ms_in = max(r[2] for r in per_rank) if per_rank else ms_ingest
         out = {
-            "metric": "512x512 tiles/sec over 16k x 16k FITS", "value": value, "unit": "tiles/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
+            "metric": wl["metric"], "value": value, "unit": "tiles/s", "n_gpus": n_gpus,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "synthetic %dx%d 1-chan FITS (S16k recipe, seed 20260104), 512x512 tiles step 0.8 "
-                                   "(%d tiles), zscale+minmax, yolov8l nc=5 seeded weights, imgsz 512, conf 0.7, iou 0.5, "
-                                   "merge 0.3/0.8, per-tile IoU merge + cross-tile merge" % (args.size, args.size, ntiles),
-                       "tiles": ntiles, "tile_batch": args.batch, "parallelism": "tile-sharded x%d" % world,
-                       "sources_in_catalog": len(src), "tiles_skipped": stats["skipped"],
+            "config": {"workload": "synthetic %dx%d 1-chan FITS (S%s recipe, seed %d), %dx%d tiles step %.1f (%d tiles), %s, "
+                                   "yolov8l nc=5 seeded weights, imgsz %d, conf 0.7, iou 0.5, merge 0.3/0.8, per-tile IoU merge + "
+                                   "cross-tile merge" % (size, size, "32k" if args.config == "c5" else "16k", wl["seed"], wl["tile"],
+                                                         wl["tile"], wl["step"], ntiles, wl["pre"], wl["imgsz"]),
+                       "tiles": ntiles, "tile_batch": batch, "parallelism": "tile-sharded x%d" % world,
+                       "backend": (dist.get_backend() if world > 1 else "none"),
+                       "sources_in_catalog": len(cat), "tiles_skipped": stats["skipped"],
                        "merge_host_ms": stats.get("merge_host_ms"), "merge_d2h_ms": stats.get("merge_d2h_ms"),
-                       "per_tile_detections": stats["per_tile_detections"]},
-            "conv_stack_mfma_frac_whole_job": value * FLOP_PER_TILE_512 / 1e12 / (PEAK_FP16_DENSE_TFLOPS * world),
+                       "per_tile_detections": stats["per_tile_detections"],
+                       "degenerate_boxes_dropped": stats.get("degenerate_boxes", 0),
+                       "candidate_overflow_tiles": stats.get("cand_overflow_tiles", 0)},
+            "conv_stack_mfma_frac_whole_job": value * wl["flop"] / 1e12 / (PEAK_FP16_DENSE_TFLOPS * world),
             "step_split_ms_rank0": {k: 1000.0 * v / args.steps for k, v in tsplit.items()},
+            # host-inclusive view (never `value`): FITS memory map -> H2D of this rank's regions -> on-device byte swap
+            "ms_ingest": ms_in, "ingest_mb_rank0": src.bytes_uploaded / 1e6,
+            "tiles_per_s_incl_ingest": ntiles / ((ms_step + ms_in) * 1e-3),
         }
+        if per_rank:
+            out["per_rank"] = [{"rank": i, "tiles": int(r[3]), "local_ms": 1000.0 * r[0] / args.steps,
+                                "gather_ms": 1000.0 * r[1] / args.steps, "ingest_ms": r[2], "mosaic_mb": r[4] / 1e6}
+                               for i, r in enumerate(per_rank)]
         if prof:
             prof = [p for p in prof if p["launches"]]
             k = max(prof, key=lambda p: p["ms"])          # dominant kernel = largest share of GPU time in the forward
             if k["launches"] and k["ms"] > 0:
                 ach = k["flops"] / (k["ms"] * 1e-3) / 1e12
+                traffic, tsrc = pmc_traffic(k["kernel"])
                 out["roofline"] = {"kernel": k["kernel"], "bound": "mfma", "achieved": ach, "peak": PEAK_FP16_DENSE_TFLOPS,
-                                   "unit": "TFLOP/s", "frac": ach / PEAK_FP16_DENSE_TFLOPS, "traffic": pmc_traffic(k["kernel"]),
+                                   "unit": "TFLOP/s", "frac": ach / PEAK_FP16_DENSE_TFLOPS, "traffic": traffic,
+                                   "traffic_source": ("%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command line, "
+                                                      "2 x FETCH + WRITE; not measured in this run)" % tsrc) if tsrc else None,
                                    "flops_per_launch": k["flops"] / k["launches"],
                                    "avg_launch_ms": k["ms"] / k["launches"], "launches": k["launches"],
                                    "timing": "hipEvents around every launch of every second batch on the launch stream, over the timed region (rank 0)"}
@@ -239,12 +374,28 @@ def main():
             out["profile_stride_batches"] = 2
         if world == 1 and not args.no_cpu_baseline:
             scale, names, wd, _ = W.read_cyw(model._wpath)
-            out["cpu_baseline"] = cpu_baseline(mosaic_host, grid, (scale, names, wd))
+            out["cpu_baseline"] = cpu_baseline(mosaic_host, grid, (scale, names, wd), wl)
         print(json.dumps(out), flush=True)
+        try:
+            os.remove(fits_path)
+        except OSError:
+            pass
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus < 1:
+        log("--gpus must be >= 1")
+        return 2
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args, argv)
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

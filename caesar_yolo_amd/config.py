@@ -12,7 +12,8 @@ CONFIG = {
     'split_image_in_tiles': False,
     'tile_xsize': 256, 'tile_ysize': 256,
     'tile_xstep': 1.0, 'tile_ystep': 1.0,
-    'max_ntasks_per_worker': 100,
+    'max_ntasks_per_worker': None,     # reference: 100 (its sequential engine refuses more tiles per rank, inference.py:1151-1160);
+                                       # the batched engine has no limit: the guard applies only when a number is given
     # source finding
     'devices': ['cpu'],
     'use_multi_gpu': False,

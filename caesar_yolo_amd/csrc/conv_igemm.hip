@@ -1751,10 +1751,10 @@ hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s) {
     switch (conv_variant(p, a)) {
         case CONV_C64_PERSIST: return a.Cin == 32 ? launch_c64<32>(a, s) : launch_c64<64>(a, s);
         case CONV_PP_64: return launch_pp<2>(a, s);
-        case CONV_PP_128: { ConvArgs b2 = a; b2.dbg = getenv("CY_DBG") ? atoi(getenv("CY_DBG")) : 0; return launch_pp<4>(b2, s); }
+        case CONV_PP_128: { ConvArgs b2 = a; b2.dbg = dev_knob("CY_DBG", 0); return launch_pp<4>(b2, s); }
         case CONV_HALO16_128: return (getenv("CY_HALO_WM") && atoi(getenv("CY_HALO_WM")) == 43) ? launch_halo<4, 3>(a, s) : launch_halo<4, 2>(a, s);
         case CONV_HALO8_128: {
-            ConvArgs b2 = a; b2.dbg = getenv("CY_DBG") ? atoi(getenv("CY_DBG")) : 0;
+            ConvArgs b2 = a; b2.dbg = dev_knob("CY_DBG", 0);
             static const int v = getenv("CY_HALO_V") ? atoi(getenv("CY_HALO_V")) : 2;      // 2: two taps per barrier (default)
             if (v == 2 && (a.Cin / 64) % 2 == 0) return launch_halo2(b2, s);
             return v == 1 ? launch_halo<2, 3, 1>(b2, s) : launch_halo<2, 2>(b2, s);
@@ -2140,7 +2140,7 @@ hipError_t launch_stem_down(const StemDownArgs& a, hipStream_t s) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(stem_down_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SD_LDS);
         attr_set = true;
     }
-    StemDownArgs b2 = a; b2.dbg = getenv("CY_SD_DBG") ? atoi(getenv("CY_SD_DBG")) : 0;
+    StemDownArgs b2 = a; b2.dbg = dev_knob("CY_SD_DBG", 0);
     hipLaunchKernelGGL(stem_down_kernel, dim3((unsigned)stem_down_blocks(a)), dim3(512), SD_LDS, s, b2);
     return hipGetLastError();
 }

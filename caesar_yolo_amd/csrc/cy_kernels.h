@@ -3,8 +3,20 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace cy {
+
+// Environment switches come in two classes.  env_knob(): selection among kernels / schedules that all compute the same
+// result (CY_BATCH_INVARIANT, CY_DUAL_FORWARD, CY_STEM_FUSE, CY_WIDE_DUAL, CY_DIRECT_MIN_BLOCKS, ... -- the parity tests force
+// every variant through them), always available.  dev_knob(): developer ablation switches that SKIP work and therefore
+// invalidate results (CY_DBG, CY_SD_DBG): read only in a diagnostic build (-DCY_DEV_KNOBS=1, `CY_STAMPS=1 python
+// __graft_entry__.py --force`); in the product binary they are the constant default.
+#ifndef CY_DEV_KNOBS
+#define CY_DEV_KNOBS 0
+#endif
+inline int env_knob(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+inline int dev_knob(const char* name, int dflt) { return CY_DEV_KNOBS ? env_knob(name, dflt) : dflt; }
 
 enum Precision { PREC_F16 = 0, PREC_F32 = 1 };
 
@@ -107,6 +119,7 @@ struct NmsArgs {
     // workspace
     uint64_t* keys;          // [B][cap_pow2]
     uint64_t* mask;          // [B][cap][cap/64]
+    int* counters;           // context counters (cy_detect_counters) or null: [1] += 1 for a tile whose candidates overflowed cap
 };
 hipError_t launch_nms(const NmsArgs& a, hipStream_t s);
 
@@ -115,6 +128,7 @@ struct MergeArgs {          // Analyzer.process_detections on device
     float score_thr; double soft, hard;
     float* out; int* out_count; int* out_src;    // [B][max_det][6], [B], [B][max_det] (index into det rows)
     int* err;               // [B] number of degenerate boxes dropped (reference would assert)
+    int* counters;          // context counters or null: [0] += degenerate boxes dropped
 };
 hipError_t launch_iou_merge(const MergeArgs& a, hipStream_t s);
 

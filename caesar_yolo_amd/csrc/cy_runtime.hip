@@ -45,6 +45,8 @@ struct cy_ctx {
     hipStream_t s_pre = nullptr, s_post = nullptr;      // side streams of the pipelined cy_detect_tiles
     hipEvent_t ev_call = nullptr, ev_pre[2] = {nullptr, nullptr}, ev_fwd[2] = {nullptr, nullptr}, ev_post[2] = {nullptr, nullptr};
     unsigned long batches = 0;                          // cy_detect_tiles calls since load / flush
+    bool mosaic_dirty = true;                           // cy_mosaic_prepare ran on the caller's stream since the last cy_detect_tiles
+    int* counters = nullptr;                            // device: [0] degenerate boxes dropped by the IoU merge, [1] tiles whose candidates overflowed `cap`
     // optional per-launch timing of the forward ops (hipEvents on the caller's stream)
     bool profiling = false;
     bool split_last = false;                             // the last forward ran as two half-batches (debug reads see only one)
@@ -92,6 +94,7 @@ void free_all(cy_ctx* c) {
         for (void* p : ptrs) if (p) hipFree(p);
         b = cy_ctx::StageBufs();
     }
+    if (c->counters) { hipFree(c->counters); c->counters = nullptr; }
     if (c->s_pre) { hipStreamDestroy(c->s_pre); c->s_pre = nullptr; }
     if (c->s_post) { hipStreamDestroy(c->s_post); c->s_post = nullptr; }
     hipEvent_t* evs[] = {&c->ev_call, &c->ev_pre[0], &c->ev_pre[1], &c->ev_fwd[0], &c->ev_fwd[1], &c->ev_post[0], &c->ev_post[1]};
@@ -242,7 +245,10 @@ int upload_weights(cy_ctx* c, const void* buf, size_t nbytes) {
     c->ws_bytes = act;
     HIPCHK(c, hipMalloc(&c->ws, c->ws_bytes));
     const int A = cy_num_anchors(g.max_h, g.max_w);
-    c->cap = g.max_cand > 0 ? g.max_cand : 8192;
+    // candidates per tile: ultralytics keeps at most max_nms = 30000 by score; with cap >= the anchor count of the largest
+    // letterboxed tile an overflow cannot happen (8400 anchors at 640x640).  A smaller explicit max_cand is honoured, and a
+    // tile that overflows it is counted (cy_detect_counters) -- its surplus candidates are dropped in arrival order.
+    c->cap = g.max_cand > 0 ? g.max_cand : A;
     if (c->cap > 30000) c->cap = 30000;
     c->cap = (c->cap + 63) / 64 * 64;
     c->cap_pow2 = 1; while (c->cap_pow2 < c->cap) c->cap_pow2 <<= 1;
@@ -264,6 +270,8 @@ int upload_weights(cy_ctx* c, const void* buf, size_t nbytes) {
         HIPCHK(c, hipMalloc(&b.pre_histeq, Bm * 3 * 520 * sizeof(double)));
         HIPCHK(c, hipMalloc(&b.pre_scratch, c->pre_scratch_elems * sizeof(double)));
     }
+    HIPCHK(c, hipMalloc(&c->counters, 4 * sizeof(int)));
+    HIPCHK(c, hipMemset(c->counters, 0, 4 * sizeof(int)));
     // side streams at the LOWEST priority: preprocessing and decode/NMS/merge fill the gaps of the conv stack on the caller's
     // stream instead of competing with it for CUs (CY_SIDE_PRIO=0 restores default-priority streams)
     int prio_lo = 0, prio_hi = 0;
@@ -380,6 +388,7 @@ size_t cy_pred_elems(const cy_ctx* c, int B, int H, int W) {
 int cy_mosaic_prepare(cy_ctx* c, float* d_data, size_t n, int big_endian, void* stream) {
     if (!c || !d_data) return fail(c, CY_ERR_ARG, "null argument");
     HIPCHK(c, launch_mosaic_prepare(d_data, n, big_endian, (hipStream_t)stream));
+    c->mosaic_dirty = true;
     return CY_OK;
 }
 
@@ -802,6 +811,7 @@ int cy_decode_nms(cy_ctx* c, const float* d_pred, int B, int H, int W, int h0, i
     n.padw = py_round_half_even((W - w0 * gain) / 2 - 0.1); n.padh = py_round_half_even((H - h0 * gain) / 2 - 0.1);
     n.w0 = w0; n.h0 = h0;
     n.det = d_det; n.det_anchor = d_det_anchor; n.det_count = d_count; n.keys = c->S().keys; n.mask = nullptr;
+    n.counters = c->counters;
     HIPCHK(c, launch_nms(n, s));
     return CY_OK;
 }
@@ -813,6 +823,7 @@ int cy_iou_merge(cy_ctx* c, const float* d_det, const int* d_count, int B, float
     MergeArgs m{};
     m.det = d_det; m.det_count = d_count; m.B = B; m.max_det = CY_MAX_DET; m.score_thr = score_thr; m.soft = soft; m.hard = hard;
     m.out = d_out; m.out_count = d_out_count; m.out_src = d_out_src ? d_out_src : c->S().out_src; m.err = c->S().merge_err;
+    m.counters = c->counters;
     HIPCHK(c, launch_iou_merge(m, (hipStream_t)stream));
     return CY_OK;
 }
@@ -834,9 +845,14 @@ int cy_detect_tiles(cy_ctx* c, const float* d_mosaic, int MH, int MW, const int*
     const bool reuse = c->batches >= 2;
     c->slot = sl;
     int rc = CY_OK;
-    // order the side streams after whatever the caller already queued on `stream` (e.g. cy_mosaic_prepare)
-    HIPCHK(c, hipEventRecord(c->ev_call, sm));
-    HIPCHK(c, hipStreamWaitEvent(c->s_pre, c->ev_call, 0));
+    // order the side streams after whatever the caller already queued on `stream` -- only where that matters: the first batch
+    // after load / flush, or after cy_mosaic_prepare.  Later batches are ordered by ev_fwd / ev_post alone, so that the
+    // preprocessing of batch i does not wait for the forward of batch i-1 that is already queued on `stream`.
+    if (c->batches == 0 || c->mosaic_dirty) {
+        HIPCHK(c, hipEventRecord(c->ev_call, sm));
+        HIPCHK(c, hipStreamWaitEvent(c->s_pre, c->ev_call, 0));
+        c->mosaic_dirty = false;
+    }
     if (reuse) HIPCHK(c, hipStreamWaitEvent(c->s_pre, c->ev_fwd[sl], 0));
     rc = cy_preproc(c, d_mosaic, MH, MW, h_tiles, B, th, tw, imgsz, cfg, c->S().netin, d_status, c->s_pre);
     if (rc) { c->slot = 0; return rc; }
@@ -867,6 +883,17 @@ int cy_detect_flush(cy_ctx* c, void* stream) {
         HIPCHK(c, hipStreamWaitEvent(sm, c->ev_post[sl], 0));
         HIPCHK(c, hipStreamWaitEvent(sm, c->ev_pre[sl], 0));
     }
+    c->batches = 0;                  // the next call starts a new pipeline: it orders the side streams behind `stream` again
+    return CY_OK;
+}
+
+int cy_detect_counters(cy_ctx* c, long long* out4, int reset) {
+    if (!c || !c->loaded || !out4) return fail(c, CY_ERR_ARG, "bad arguments");
+    int h[4] = {0, 0, 0, 0};
+    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipMemcpy(h, c->counters, sizeof(h), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 4; ++i) out4[i] = h[i];
+    if (reset) HIPCHK(c, hipMemset(c->counters, 0, sizeof(h)));
     return CY_OK;
 }
 

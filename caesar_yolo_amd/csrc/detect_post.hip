@@ -95,7 +95,7 @@ __global__ __launch_bounds__(NMS_NT) void nms_kernel(const NmsArgs a, int cap_po
     __shared__ int kslot[MAXDET];
     const int b = blockIdx.x, tid = threadIdx.x;
     int n = a.cand_count[b];
-    if (n > a.cap) n = a.cap;
+    if (n > a.cap) { n = a.cap; if (tid == 0 && a.counters) atomicAdd(a.counters + 1, 1); }
     if (n == 0) { if (tid == 0) a.det_count[b] = 0; return; }
     int np2 = 64;
     while (np2 < n) np2 <<= 1;
@@ -323,6 +323,7 @@ __global__ __launch_bounds__(256) void iou_merge_kernel(const MergeArgs a) {
         }
         a.out_count[b] = nout;
         a.err[b] = nerr;
+        if (nerr && a.counters) atomicAdd(a.counters, nerr);
     }
 }
 

@@ -48,7 +48,7 @@ class Analyzer(object):
         if image_id:
             self.image_id = image_id
         self.image_xmin, self.image_ymin = xmin, ymin
-        dev = None if str(self.device) in ("cpu", "") else self.device
+        dev = None if str(self.device) == "" else self.device          # 'cpu' -> this process's GPU (model._dev_index)
         try:
             det = self.model.engine(dev)
             dp = self.config.get('preprocess_fcn')

@@ -115,8 +115,36 @@ def partition_tiles(grid, imgsz, world, batch=256):
     return pack(hi)
 
 
+class MosaicSource(object):
+    """The image on the HOST (numpy array or memmap of the FITS payload, file byte order) from which a rank uploads only
+    the regions its tiles touch: SURVEY.md section 8(e) "each GPU holds ... only its row-band of the mosaic (+ overlap
+    halo)"; the reference reads only the tile, caesar_yolo/utils.py:368-394.  A region already resident is reused."""
+
+    def __init__(self, host, big_endian=None):
+        self.host = host
+        self.ny, self.nx = host.shape
+        self.big_endian = (host.dtype.byteorder == ">") if big_endian is None else bool(big_endian)
+        self.regions = []                       # (x0, x1, y0, y1, device tensor)
+        self.bytes_uploaded = 0
+
+    def region(self, det, x0, x1, y0, y1):
+        """-> (device tensor [y1-y0 (or more), ...], origin x, origin y) covering [x0,x1) x [y0,y1)."""
+        for a0, a1, b0, b1, t in self.regions:
+            if a0 <= x0 and x1 <= a1 and b0 <= y0 and y1 <= b1:
+                return t, a0, b0
+        arr = np.ascontiguousarray(self.host[y0:y1, x0:x1])
+        t = det.mosaic_to_device(arr, big_endian=self.big_endian)
+        self.regions.append((x0, x1, y0, y1, t))
+        self.bytes_uploaded += arr.size * 4
+        return t, x0, y0
+
+
 class TileEngine(object):
-    """Runs the per-tile path for this rank's share of a tile grid and merges all ranks' detections."""
+    """Runs the per-tile path for this rank's share of a tile grid and merges all ranks' detections.
+
+    `mosaic_dev` is either the whole image resident on the device, or a MosaicSource: then only the bounding box of each
+    shape-class segment of THIS rank's tiles is uploaded (the partition cuts the tile list into contiguous runs, so a
+    rank's full-size tiles are a band of rows) and tile origins are rebased to it."""
 
     def __init__(self, detector, mosaic_dev, grid, pre_cfg, imgsz, conf, iou, soft, hard, rank=0, world=1, batch=64):
         self.det, self.mosaic, self.grid = detector, mosaic_dev, [tuple(int(v) for v in t) for t in grid]
@@ -129,21 +157,27 @@ class TileEngine(object):
         self.cap_tiles = max(max(self.counts), 1)
         self.my = parts[rank]
         n_my = self.counts[rank]
-        # launch plan, built once: (th, tw, B, ctypes origins, first row)
+        # launch plan, built once: (th, tw, B, origins, first row, device image the origins refer to)
         self.plan, row = [], 0
         for (th, tw), tids in self.my:
+            img, ox, oy = self.mosaic, 0, 0
+            if isinstance(self.mosaic, MosaicSource) and tids:
+                g = [self.grid[t] for t in tids]
+                img, ox, oy = self.mosaic.region(detector, min(t[0] for t in g), max(t[1] for t in g),
+                                                 min(t[2] for t in g), max(t[3] for t in g))
             nb = (len(tids) + self.batch - 1) // self.batch        # equal-sized batches (198 tiles -> 50,50,49,49, not 64,64,64,6)
             i = 0
             for k in range(nb):
                 n = len(tids) // nb + (1 if k < len(tids) % nb else 0)
                 chunk = tids[i:i + n]
                 i += n
-                xy = [(self.grid[t][0], self.grid[t][2]) for t in chunk]
-                self.plan.append((th, tw, len(chunk), xy, row))
+                xy = [(self.grid[t][0] - ox, self.grid[t][2] - oy) for t in chunk]
+                self.plan.append((th, tw, len(chunk), xy, row, img))
                 row += len(chunk)
         dev = detector.tdev
-        # fixed-capacity record buffer: [tile][300*6 floats | count | status | tile id]
-        self.rec = torch.zeros((self.cap_tiles, L.CY_MAX_DET * 6 + 3), dtype=torch.float32, device=dev)
+        # fixed-capacity record buffer: [tile][300*6 floats | count | status | tile id]; one extra row at the end carries this
+        # rank's event counters (degenerate boxes dropped, tiles whose candidates overflowed), so ONE collective moves all
+        self.rec = torch.zeros((self.cap_tiles + 1, L.CY_MAX_DET * 6 + 3), dtype=torch.float32, device=dev)
         # per-tile outputs of this rank, in processing order (each batch writes its own slice: batches overlap)
         self.det_all = torch.zeros((max(n_my, 1), L.CY_MAX_DET, 6), dtype=torch.float32, device=dev)
         self.cnt_all = torch.zeros((max(n_my, 1),), dtype=torch.int32, device=dev)
@@ -155,9 +189,9 @@ class TileEngine(object):
 
     def run_local(self):
         """Enqueue every batch of this rank's tiles (software-pipelined inside the library); results stay on device."""
-        for th, tw, B, xy, row in self.plan:
+        for th, tw, B, xy, row, img in self.plan:
             out = (self.det_all[row:row + B], self.cnt_all[row:row + B], self.st_all[row:row + B])
-            self.det.detect_tiles(self.mosaic, xy, th, tw, self.imgsz, self.pre_cfg, self.conf, self.iou,
+            self.det.detect_tiles(img, xy, th, tw, self.imgsz, self.pre_cfg, self.conf, self.iou,
                                   self.soft, self.hard, out=out, flush=False)
         if hasattr(self.det, "flush"):
             self.det.flush()
@@ -167,6 +201,9 @@ class TileEngine(object):
             self.rec[:n, -3] = self.cnt_all[:n].float()
             self.rec[:n, -2] = self.st_all[:n].float()
             self.rec[:n, -1] = self.tid_all[:n]
+        if hasattr(self.det, "counters"):
+            c = self.det.counters(reset=True)
+            self.rec[self.cap_tiles, :2] = torch.tensor([c["degenerate_boxes"], c["cand_overflow_tiles"]], dtype=torch.float32).to(self.rec.device)
         return n
 
     def gather(self):
@@ -211,6 +248,11 @@ class TileEngine(object):
         keep = torch.arange(L.CY_MAX_DET, device=g.device)[None, :] < cnt[:, None]
         det = rows[:, :L.CY_MAX_DET * 6].reshape(-1, L.CY_MAX_DET, 6)[keep]          # [Ndet, 6] in tile-id order
         stats = {"tiles": int(rows.shape[0]), "skipped": int((status_h != 0).sum()), "per_tile_detections": int(cnt_h.sum())}
+        ev = g[:, self.cap_tiles, :2].sum(0).cpu().numpy()                         # the ranks' event counters (last row)
+        stats["degenerate_boxes"], stats["cand_overflow_tiles"] = int(ev[0]), int(ev[1])
+        if ev[0] or ev[1]:
+            logger.warning("%d degenerate boxes dropped before the IoU merge (the reference aborts on them: utils.py:78-81); "
+                           "%d tiles exceeded the candidate capacity (raise max_cand)" % (int(ev[0]), int(ev[1])))
         import time as _t
         t0 = _t.time()
         det_h = np.ascontiguousarray(det.cpu().numpy(), np.float32)
@@ -222,6 +264,26 @@ class TileEngine(object):
         stats["merge_host_ms"] = 1e3 * (_t.time() - t1)
         stats["merge_d2h_ms"] = 1e3 * (t1 - t0)
         return out, stats
+
+    def tile_results(self, names, image_id):
+        """Per-tile `Analyzer.results` dicts of every tile that was not rejected, keyed by tile id: what each TileTask's
+        Analyzer holds after predict (caesar_yolo/evaluation.py:418-469 with obj_name_tag "t<tid>" and the tile origin,
+        caesar_yolo/inference.py:107, :230-232).  Needs gather() first; rank 0 writes the per-tile files from it."""
+        g = self.gathered
+        rows = g[:, :self.cap_tiles].reshape(-1, g.shape[-1]).cpu().numpy()
+        out = {}
+        for r, part in enumerate(self._parts):
+            row = 0
+            for _, tids in part:
+                for t in tids:
+                    rec = rows[r * self.cap_tiles + row]
+                    row += 1
+                    if int(rec[-2]) != 0:
+                        continue
+                    x0, x1, y0, y1 = self.grid[t]
+                    dd = rec[:L.CY_MAX_DET * 6].reshape(L.CY_MAX_DET, 6)[:int(rec[-3])]
+                    out[t] = {"image_id": image_id, "objs": objs_from_detections(dd, names, x1 - x0, y1 - y0, x0, y0, "t%d" % t)}
+        return out
 
     def catalog(self, names):
         """-> (the reference's list of source dicts, stats)."""
@@ -303,7 +365,9 @@ class SFinder(object):
         self.stats = {}
 
     # ---- shared
-    def _load_mosaic(self):
+    def _load_mosaic(self, resident=True):
+        """resident=True: the whole image on the device (single frame).  False: a MosaicSource over the memory-mapped
+        FITS payload; the tile engine then uploads only this rank's regions."""
         path = self.config['image_path']
         if os.path.splitext(path)[1] != '.fits':
             logger.error("Only FITS images are supported on the HIP path")
@@ -316,6 +380,8 @@ class SFinder(object):
         self.ny, self.nx = data.shape
         self._beam_info()
         det = self.model.engine(self._device())
+        if not resident:
+            return det, MosaicSource(data, big_endian=True)
         return det, det.mosaic_to_device(data, big_endian=True)
 
     def _beam_info(self):
@@ -380,13 +446,35 @@ class SFinder(object):
                                     merged_tag=False)
         return 0
 
+    def _write_tile_outputs(self, eng, mosaic):
+        """--save_tile_catalog / --save_tile_region / --save_tile_img (caesar_yolo/inference.py:330-350, :220-229,
+        :1020-1022): one catalog_<id>_tid<N>.json / .reg / timg_<id>_tid<N>.fits per tile that ran.  The reference writes
+        them from each worker's Analyzer; here rank 0 writes the same files after the gather."""
+        c = self.config
+        sj, sr, si = c.get('save_tile_catalog', False), c.get('save_tile_region', False), c.get('save_tile_img', False)
+        if not (sj or sr or si):
+            return
+        res = eng.tile_results(self.model.names, self.image_id)
+        for tid, r in sorted(res.items()):
+            stem = str(self.image_id) + '_tid' + str(tid)
+            if sj:
+                with open('catalog_' + stem + '.json', 'w') as fp:
+                    json.dump(r, fp, indent=2, sort_keys=True)
+            if sr:
+                utils.write_ds9_regions('catalog_' + stem + '.reg', r["objs"], merged_tag=False)
+            if si and isinstance(mosaic, MosaicSource):
+                x0, x1, y0, y1 = eng.grid[tid]
+                tile = np.array(mosaic.host[y0:y1, x0:x1], dtype=np.float32)
+                tile[~np.isfinite(tile)] = 0                       # read_fits_crop value semantics (utils.py:394)
+                utils.write_fits_image('timg_' + stem + '.fits', tile)
+
     # ---- tiled (reference :578-658)
     def run_parallel(self):
         import torch.distributed as dist
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         rank = dist.get_rank() if world > 1 else 0
         t0 = time.time()
-        m = self._load_mosaic()
+        m = self._load_mosaic(resident=False)
         if m is None:
             return -1
         det, mosaic = m
@@ -400,9 +488,18 @@ class SFinder(object):
         conf, iou, soft, hard = self._thr()
         eng = TileEngine(det, mosaic, grid, self._pre_cfg(), c['img_size'], conf, iou, soft, hard, rank, world,
                          c.get('tile_batch', 64))
+        # caesar_yolo/inference.py:1151-1160: the reference refuses a run in which a worker holds more than
+        # max_ntasks_per_worker tiles (its default, 100, would refuse BASELINE configs 3-5 at any rank count up to 16).  The
+        # batched engine has no such limit, so the guard applies only when the option was given explicitly (run.py passes
+        # None otherwise); then it behaves like the reference: warning, -1.
+        cap = c.get('max_ntasks_per_worker')
+        if cap is not None and max(eng.counts) > cap:
+            logger.warning("[PROC %d] Too many tasks per worker exceeded (thr=%d)!" % (rank, cap))
+            return -1
         eng.run_local()
         eng.gather()
         if rank == 0:
+            self._write_tile_outputs(eng, mosaic)
             src, self.stats = eng.catalog(self.model.names)
             self.sources = {"sources": src}
             if self.write_to_json:

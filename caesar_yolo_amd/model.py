@@ -12,12 +12,16 @@ PyTorch is used only for device memory and streams; all arithmetic is in libcaes
 path: constructing a detector without a visible GPU, or without the built library, raises.
 """
 import ctypes as C
+import logging
 import os
 import numpy as np
 import torch
 
 from . import lib as L
 from . import weights as W
+
+
+_CPU_WARNED = False
 
 
 def _dev_index(device):
@@ -31,7 +35,16 @@ def _dev_index(device):
     if s.isdigit():
         return int(s)
     if s == "cpu":
-        raise L.CyError("device='cpu' requested: this detector has no CPU path (use the reference for CPU runs)")
+        # The reference's DEFAULT is --devices=cpu (scripts/run.py:130) and Analyzer passes it straight to the model call
+        # (caesar_yolo/evaluation.py:183).  This build has no CPU path; raising here would make every tile fail inside the
+        # reference's try/except (evaluation.py:194-196) and the run would "succeed" with an empty catalog.  So 'cpu' selects
+        # the process's GPU (LOCAL_RANK under torch.distributed, else 0) -- the same rule scripts/run.py applies -- and says so once.
+        global _CPU_WARNED
+        if not _CPU_WARNED:
+            logging.getLogger("caesar_yolo_amd").warning(
+                "device='cpu' requested: this build has no CPU path, running on GPU %s instead", os.environ.get("LOCAL_RANK", "0"))
+            _CPU_WARNED = True
+        return int(os.environ.get("LOCAL_RANK", "0"))
     raise L.CyError("unknown device %r" % (device,))
 
 
@@ -163,6 +176,12 @@ class HipDetector(object):
     def flush(self):
         """Order the current stream behind every batch queued by detect_tiles (they run on internal side streams)."""
         self._chk(self.lib.cy_detect_flush(self.ctx, self._stream()))
+
+    def counters(self, reset=False):
+        """-> dict(degenerate_boxes, cand_overflow_tiles) accumulated since the last reset (synchronises the device)."""
+        out = (C.c_longlong * 4)()
+        self._chk(self.lib.cy_detect_counters(self.ctx, out, int(bool(reset))))
+        return {"degenerate_boxes": int(out[0]), "cand_overflow_tiles": int(out[1])}
 
     def detect_tiles(self, mosaic, tiles_xy, th, tw, imgsz, cfg, conf, iou, soft, hard, out=None, flush=True):
         """Whole per-tile path for B same-shape tiles.  Returns (det [B,300,6], count [B], status [B]) on device.

@@ -6,8 +6,9 @@ kernels (csrc/cy_preproc.hip) execute per tile in HBM.  `DataPreprocessor.progra
 C-ABI `cy_preproc_cfg` (one op list per output channel).
 
 Only the stages reachable from the reference CLI exist here: BkgSubtractor, SigmaClipShifter,
-SigmaClipper, ChanResizer, ZScaleTransformer, Chan3Trasformer (sic), MinMaxNormalizer.  Options the device kernels do
-not implement (per-channel `chid` selection) raise at construction time instead of silently diverging.
+SigmaClipper, ChanResizer, ZScaleTransformer, Chan3Trasformer (sic), MinMaxNormalizer.  Per-channel stage selection
+(`chid`, from --bkg_chid / --clip_chid, scripts/run.py:89, :98, :275-281) lowers the stage into that channel's program
+only: the reference skips the other channels (caesar_yolo/preprocessing.py:653, :712, :766).
 """
 from . import lib as L
 
@@ -17,20 +18,26 @@ class _Stage(object):
         raise NotImplementedError
 
 
-def _no_chid(chid):
-    if chid != -1:
-        raise NotImplementedError("chid != -1 (single-channel stage selection) is not implemented on the device path")
+def _targets(progs, chid):
+    """The channel programs a stage with this `chid` is appended to (-1: all three)."""
+    chid = int(chid)
+    if chid == -1:
+        return progs
+    if chid not in (0, 1, 2):
+        # the reference would simply never match `i == chid` and the stage would do nothing; say so instead
+        raise ValueError("chid must be -1 or a channel index 0..2 (got %r)" % (chid,))
+    return [progs[chid]]
 
 
 class BkgSubtractor(_Stage):
     """caesar_yolo/preprocessing.py:591-658"""
 
     def __init__(self, sigma=3, use_mask_box=False, mask_fract=0.7, chid=-1, **kw):
-        _no_chid(chid)
-        self.sigma, self.use_mask_box, self.mask_fract = float(sigma), bool(use_mask_box), float(mask_fract)
+        self.sigma, self.use_mask_box, self.mask_fract, self.chid = float(sigma), bool(use_mask_box), float(mask_fract), int(chid)
+        _targets([[], [], []], chid)
 
     def lower(self, progs):
-        for p in progs:
+        for p in _targets(progs, self.chid):
             p.append((L.OP_BKG, self.sigma, self.mask_fract, 0.0, int(self.use_mask_box)))
 
 
@@ -38,11 +45,11 @@ class SigmaClipShifter(_Stage):
     """caesar_yolo/preprocessing.py:664-717"""
 
     def __init__(self, sigma=1.0, chid=-1, **kw):
-        _no_chid(chid)
-        self.sigma = float(sigma)
+        self.sigma, self.chid = float(sigma), int(chid)
+        _targets([[], [], []], chid)
 
     def lower(self, progs):
-        for p in progs:
+        for p in _targets(progs, self.chid):
             p.append((L.OP_SHIFT, self.sigma, 0.0, 0.0, 0))
 
 
@@ -50,11 +57,11 @@ class SigmaClipper(_Stage):
     """caesar_yolo/preprocessing.py:723-771"""
 
     def __init__(self, sigma_low=10.0, sigma_up=10.0, chid=-1, **kw):
-        _no_chid(chid)
-        self.sigma_low, self.sigma_up = float(sigma_low), float(sigma_up)
+        self.sigma_low, self.sigma_up, self.chid = float(sigma_low), float(sigma_up), int(chid)
+        _targets([[], [], []], chid)
 
     def lower(self, progs):
-        for p in progs:
+        for p in _targets(progs, self.chid):
             p.append((L.OP_CLIP, self.sigma_low, self.sigma_up, 0.0, 0))
 
 

@@ -33,7 +33,9 @@ typedef struct cy_config {
     int precision;            /* cy_precision */
     int max_batch;            /* tiles per launch the workspace is sized for */
     int max_h, max_w;         /* largest letterboxed network input (multiple of 32) */
-    int max_cand;             /* candidate capacity per tile before NMS (<= 30000 = ultralytics max_nms); 0 -> 8192 */
+    int max_cand;             /* candidate capacity per tile before NMS (<= 30000 = ultralytics max_nms); 0 -> the anchor
+                                 count of a max_h x max_w input (no overflow possible); a tile that overflows a smaller
+                                 explicit capacity is counted in cy_detect_counters */
 } cy_config;
 
 /* Preprocessing program: the CLI-fixed stage order of scripts/run.py:272-302, one op list per output channel.
@@ -129,6 +131,13 @@ int cy_detect_tiles(cy_ctx* ctx, const float* d_mosaic, int MH, int MW, const in
                     float* d_out, int* d_out_count, int* d_status, void* stream);
 
 int cy_detect_flush(cy_ctx* ctx, void* stream);
+
+/* events the reference would not survive silently, accumulated over cy_decode_nms / cy_iou_merge / cy_detect_tiles calls:
+ * out4[0] degenerate boxes (x1 >= x2 or y1 >= y2) dropped before the IoU merge -- the reference aborts on them inside
+ * get_iou's assert (caesar_yolo/utils.py:78-81); out4[1] tiles with more candidates than the
+ * context's capacity (ultralytics keeps the top max_nms = 30000 by score; here the surplus is dropped in arrival order, so
+ * a non-zero count means "raise max_cand"); out4[2..3] reserved.  Synchronises the device.  reset != 0 clears them. */
+int cy_detect_counters(cy_ctx* ctx, long long* out4, int reset);
 
 /* single fused Conv+bias+SiLU layer on caller tensors (kernel-level parity tests).
  * d_in [B][Hi][Wi][Cin], d_out [B][Ho][Wo][Cout] in the context precision; h_w [Cout][Cin][k][k], h_b [Cout] fp32;

@@ -236,6 +236,33 @@ def gen_preproc(outdir):
     print("preproc.npz keys:", len(out))
 
 
+CHID_PIPELINES = {
+    # --bkg_chid / --clip_chid (scripts/run.py:89, :98, :275-281): the stage touches ONE channel, the others pass through
+    "bkg_chid0": lambda: [rpp.BkgSubtractor(sigma=3, chid=0)],
+    "shiftclip_chid1_minmax": lambda: [rpp.SigmaClipShifter(sigma=1, chid=1), rpp.SigmaClipper(sigma_low=10, sigma_up=10, chid=1),
+                                       rpp.MinMaxNormalizer(norm_min=0, norm_max=255)],
+    "bkg_chid2_zscale_minmax": lambda: [rpp.BkgSubtractor(sigma=3, chid=2), rpp.ZScaleTransformer(contrasts=[0.25, 0.25, 0.25]),
+                                        rpp.MinMaxNormalizer(norm_min=0, norm_max=255)],
+    "bkgbox_chid1_clip_chid0": lambda: [rpp.BkgSubtractor(sigma=3, use_mask_box=True, mask_fract=0.7, chid=1),
+                                        rpp.SigmaClipper(sigma_low=1, sigma_up=3, chid=0)],
+}
+
+
+def gen_preproc_chid(outdir):
+    """Per-channel stage selection on the inputs preproc.npz already holds (same arrays): full (H,W,3) outputs."""
+    g = np.load(os.path.join(outdir, "preproc.npz"))
+    out = {}
+    for iname in ("galaxy", "syn192", "rag"):
+        img = g["in/" + iname]
+        for pname, mk in CHID_PIPELINES.items():
+            with quiet():
+                res = rpp.DataPreprocessor(mk())(cube(img))
+            assert res is not None and res.shape == img.shape + (3,)
+            out["out/%s/%s" % (iname, pname)] = res
+    np.savez_compressed(os.path.join(outdir, "preproc_chid.npz"), **out)
+    print("preproc_chid.npz keys:", len(out))
+
+
 # ---------------------------------------------------------------- tiles + neighbours
 TILE_CASES = {
     "c2_16k_512_1.0": (0, 16383, 0, 16383, 512, 512, 1.0, 1.0),
@@ -481,7 +508,40 @@ def run_serial(outdir, scratch):
     print("catalog_serial.json: model saw", model.seen[0]["shape"], model.seen[0]["min"], model.seen[0]["max"])
 
 
-def run_tiled(outdir, scratch, tag, nx, ny, tsize, step, seed, nper=10):
+def dense_edge_dets(rng, grid, dets, nlong=14):
+    """Sources that cross tile borders on purpose: long thin rectangles in MOSAIC coordinates, cut by every tile they
+    touch (each piece ends exactly on a tile border, so it is edge-flagged and overlaps its neighbours' pieces) -> merge
+    chains over three and more tiles; every other one is given twins of EQUAL area in neighbouring tiles (ties in the
+    largest-area selection, inference.py:849-851: first wins) and alternating classes (the cross-tile merge ignores class)."""
+    nx = max(t[1] for t in grid)
+    ny = max(t[3] for t in grid)
+    for k in range(nlong):
+        horizontal = (k % 2 == 0)
+        if horizontal:      # bands in the upper half, 60 px apart: chains do not touch each other
+            y0 = 12.0 + 60.0 * (k // 2) + float(rng.uniform(0, 8)); h = float(rng.uniform(8, 22))
+            x0 = float(rng.uniform(0, nx * 0.3)); x1 = float(rng.uniform(nx * 0.6, nx - 1))
+            gx0, gx1, gy0, gy1 = x0, x1, y0, y0 + h
+        else:               # columns in the lower half, 90 px apart
+            x0 = 20.0 + 90.0 * (k // 2) + float(rng.uniform(0, 8)); w = float(rng.uniform(8, 22))
+            y0 = float(rng.uniform(ny * 0.56, ny * 0.62)); y1 = float(rng.uniform(ny * 0.9, ny - 1))
+            gx0, gx1, gy0, gy1 = x0, x0 + w, y0, y1
+        score = float(rng.uniform(0.75, 0.99))
+        for ti, t in enumerate(grid):
+            cx0, cx1 = max(gx0, t[0]), min(gx1, t[1])
+            cy0, cy1 = max(gy0, t[2]), min(gy1, t[3])
+            if cx1 - cx0 < 4 or cy1 - cy0 < 4:
+                continue
+            b, sc, c = dets[ti]
+            box = [cx0 - t[0], cy0 - t[2], cx1 - t[0], cy1 - t[2]]
+            b = np.concatenate([b, np.array([box], np.float32)]) if len(b) else np.array([box], np.float32)
+            # equal scores in every piece for odd k (ties), tile-dependent scores otherwise
+            sc = np.concatenate([sc, np.array([score if k % 4 < 2 else max(0.71, score - 0.01 * (ti % 7))], np.float32)])
+            c = np.concatenate([c, np.array([float((k + ti) % 5)], np.float32)])
+            dets[ti] = (b, sc, c)
+    return dets
+
+
+def run_tiled(outdir, scratch, tag, nx, ny, tsize, step, seed, nper=10, dense=False, save_img=True):
     os.chdir(scratch)
     img = make_tile(ny, nx, seed, nsrc=80, zero_block=False, zero_strip=False)
     # tile-skip triggers: one all-zero tile (MinMaxNormalizer -> None) and one tile whose first
@@ -512,6 +572,8 @@ def run_tiled(outdir, scratch, tag, nx, ny, tsize, step, seed, nper=10):
             else:
                 b[k][3] = h - rng.uniform(0, 0.9)
         dets.append((b, s, c))
+    if dense:
+        dets = dense_edge_dets(rng, grid, dets)
     # the reference calls the model only for tiles that survive preprocessing + the row check, so
     # replay by tile id instead of call order
     class TileReplay(ReplayModel):
@@ -572,7 +634,8 @@ def run_tiled(outdir, scratch, tag, nx, ny, tsize, step, seed, nper=10):
            "config": {"score_thr": 0.7, "iou_thr": 0.5, "soft": 0.3, "hard": 0.8, "img_size": tsize}}
     with open(os.path.join(outdir, "catalog_tiled_%s.json" % tag), "w") as fp:
         json.dump(fix, fp)
-    np.savez_compressed(os.path.join(outdir, "mosaic_%s.npz" % tag), img=img)
+    if save_img:
+        np.savez_compressed(os.path.join(outdir, "mosaic_%s.npz" % tag), img=img)
     nsrc = len(json.loads(cat_text)["sources"])
     print("catalog_tiled_%s.json: %d tiles, %d skipped, %d final sources, %d merged" % (
         tag, T, sum(1 for c in called if c[1] < 0), nsrc,
@@ -584,6 +647,10 @@ def main():
     scratch = "/tmp/caesar_golden_scratch"
     os.makedirs(scratch, exist_ok=True)
     os.makedirs(outdir, exist_ok=True)
+    if len(sys.argv) > 2 and sys.argv[2] == "round2":      # additions of round 2 only (the other fixtures stay byte-identical)
+        gen_preproc_chid(outdir)
+        run_tiled(outdir, scratch, "d", 1500, 1100, 256, 0.5, 34, nper=2, dense=True, save_img=False)
+        return
     gen_preproc(outdir)
     gen_tiles(outdir, scratch)
     gen_process_detections(outdir)
@@ -591,6 +658,8 @@ def main():
     run_tiled(outdir, scratch, "a", 1300, 900, 512, 0.8, 31)
     run_tiled(outdir, scratch, "b", 1024, 1024, 256, 1.0, 32, nper=8)
     run_tiled(outdir, scratch, "c", 900, 700, 256, 0.5, 33, nper=6)
+    gen_preproc_chid(outdir)
+    run_tiled(outdir, scratch, "d", 1500, 1100, 256, 0.5, 34, nper=2, dense=True, save_img=False)
 
 
 if __name__ == "__main__":

@@ -64,7 +64,8 @@ def parse_args(argv=None):
     p.add_argument('--tile_ysize', type=int, default=512)
     p.add_argument('--tile_xstep', type=float, default=1.0)
     p.add_argument('--tile_ystep', type=float, default=1.0)
-    p.add_argument('--max_ntasks_per_worker', type=int, default=100)
+    p.add_argument('--max_ntasks_per_worker', type=int, default=None,
+                   help='refuse the run if a rank holds more tiles (reference default 100; here: no limit unless given)')
     p.add_argument('--devices', type=str, default="cpu")
     p.add_argument('--multigpu', dest='multigpu', action='store_true')
     for a in ('draw_plots', 'draw_class_label_in_caption', 'save_plots', 'save_tile_catalog', 'save_tile_region', 'save_tile_img'):
@@ -145,8 +146,12 @@ def main(argv=None):
               'score_thr': args.scoreThr, 'merge_overlap_iou_thr_soft': args.merge_overlap_iou_thr_soft,
               'merge_overlap_iou_thr_hard': args.merge_overlap_iou_thr_hard, 'outfile': args.detect_outfile,
               'outfile_json': args.detect_outfile_json, 'save_region': True, 'tile_batch': args.tile_batch,
+              'save_tile_catalog': args.save_tile_catalog, 'save_tile_region': args.save_tile_region,
+              'save_tile_img': args.save_tile_img,
               'precision': args.precision})
-    tile_max = max(args.tile_xsize, args.tile_ysize) if args.split_img_in_tiles else 0
+    if args.draw_plots or args.save_plots or args.draw_class_label_in_caption:
+        logger.warning("--draw_plots / --save_plots / --draw_class_label_in_caption: plotting is not part of this build "
+                       "(SURVEY.md section 8 f4), the flags are ignored")
     model = YOLO(args.weights, precision=args.precision, max_batch=args.tile_batch if args.split_img_in_tiles else 1,
                  max_imgsz=max(args.imgsize, 32))
     sfinder = SFinder(model, C)

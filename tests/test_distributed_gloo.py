@@ -63,7 +63,7 @@ def _worker(rank, world, tag, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("tag,world", [("a", 2), ("c", 2), ("c", 3)])
+@pytest.mark.parametrize("tag,world", [("a", 2), ("c", 2), ("c", 3), ("d", 2), ("d", 3)])
 def test_two_rank_catalog_equals_reference(tag, world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

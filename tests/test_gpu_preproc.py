@@ -132,3 +132,45 @@ def test_big512_sample_fp32():
         got = netin[0].float().cpu().numpy()[..., :3][..., ::-1].reshape(-1, 3)[::97]
         ref = (g["big512_sample/%s" % pname].astype(np.float32) / np.float32(255)).astype(np.float32)
         np.testing.assert_allclose(got, ref, rtol=0, atol=2e-7)
+
+
+CHID_PIPES = {
+    "bkg_chid0": lambda M: [M.BkgSubtractor(sigma=3, chid=0)],
+    "shiftclip_chid1_minmax": lambda M: [M.SigmaClipShifter(sigma=1, chid=1), M.SigmaClipper(sigma_low=10, sigma_up=10, chid=1),
+                                         M.MinMaxNormalizer(norm_min=0, norm_max=255)],
+    "bkg_chid2_zscale_minmax": lambda M: [M.BkgSubtractor(sigma=3, chid=2), M.ZScaleTransformer(contrasts=[0.25] * 3),
+                                          M.MinMaxNormalizer(norm_min=0, norm_max=255)],
+    "bkgbox_chid1_clip_chid0": lambda M: [M.BkgSubtractor(sigma=3, use_mask_box=True, mask_fract=0.7, chid=1),
+                                          M.SigmaClipper(sigma_low=1, sigma_up=3, chid=0)],
+}
+
+
+@pytest.mark.parametrize("pname", sorted(CHID_PIPES))
+@pytest.mark.parametrize("iname", ["galaxy", "syn192", "rag"])
+def test_chid_stage_selection_matches_reference_golden(pname, iname):
+    """--bkg_chid / --clip_chid (scripts/run.py:89, :98): compared DIRECTLY with the (H,W,3) outputs of the imported reference
+    (tests/golden/preproc_chid.npz), through the model's LetterBox/flip//255."""
+    from oracle import yolov8_ref as Y
+    det = detector("fp32", max_imgsz=640)
+    g = np.load(os.path.join(ROOT, "tests/golden/preproc.npz"))
+    gc = np.load(os.path.join(ROOT, "tests/golden/preproc_chid.npz"))
+    img = g["in/" + iname]
+    th, tw = img.shape
+    imgsz = 192 if iname == "syn192" else 256          # syn192: no resize (exact zero mask); the others go through the resize
+    mosaic, xy = _mosaic(det, [img])
+    cfg = PP.DataPreprocessor(CHID_PIPES[pname](PP)).program()
+    assert cfg.nprog == 3
+    netin, status, lb = det.preproc(mosaic, xy, th, tw, imgsz, cfg)
+    torch.cuda.synchronize()
+    assert status.cpu().tolist() == [0]
+    ref_img = gc["out/%s/%s" % (iname, pname)]
+    x, hw = Y.preprocess(ref_img, imgsz)
+    assert hw == (lb.H, lb.W)
+    got = netin[0].float().cpu().numpy()
+    ref = x[0].permute(1, 2, 0).numpy()
+    scale = 1.0
+    if (lb.new_h, lb.new_w) == (th, tw):
+        assert np.array_equal(got[..., :3] == 0, ref == 0)
+        np.testing.assert_allclose(got[..., :3], ref, rtol=3e-7, atol=1e-30)       # un-normalised pipelines: values ~1e-7, so relative
+    else:
+        np.testing.assert_allclose(got[..., :3], ref, rtol=5e-7, atol=5e-7 * scale * float(np.abs(ref).max()))

@@ -49,8 +49,13 @@ def test_stage_lowering_matches_cli_order():
     assert c3.nprog == 3 and [c3.prog[i].n for i in range(3)] == [3, 3, 2]
     assert [c3.prog[2].st[i].op for i in range(2)] == [L.OP_HISTEQ, L.OP_MINMAX]
     assert PP.DataPreprocessor([]).program().nprog == 0
-    with pytest.raises(NotImplementedError):
-        PP.SigmaClipper(10, 10, chid=1)
+    # --bkg_chid / --clip_chid: the stage goes into that channel's program only (preprocessing.py:653, :712, :766)
+    ch = PP.DataPreprocessor([PP.BkgSubtractor(sigma=3, chid=2), PP.SigmaClipper(10, 10, chid=1), PP.MinMaxNormalizer(0, 255)]).program()
+    assert ch.nprog == 3 and [ch.prog[i].n for i in range(3)] == [1, 2, 2]
+    assert [ch.prog[1].st[i].op for i in range(2)] == [L.OP_CLIP, L.OP_MINMAX]
+    assert [ch.prog[2].st[i].op for i in range(2)] == [L.OP_BKG, L.OP_MINMAX]
+    with pytest.raises(ValueError):
+        PP.SigmaClipper(10, 10, chid=3)
     with pytest.raises(RuntimeError):
         dp(np.zeros((4, 4, 3)))                   # there is no CPU preprocessing path in the product
 
@@ -113,3 +118,19 @@ def test_beam_metadata_from_header(golden_dir, tmp_path):
     h = dict(cards)
     expect = np.pi * h["BMAJ"] * h["BMIN"] / (4 * np.log(2)) / abs(h["CDELT1"] * h["CDELT2"])
     assert abs(sf.beamArea - expect) <= 1e-12 * expect and 80.0 < sf.beamArea < 90.0
+
+
+def test_generate_tiles_matches_reference_golden(golden_dir):
+    """The PRODUCT's utils.generate_tiles (not the oracle's copy) against the grids the imported reference produced
+    (tests/golden/tiles.json, oracle/gen_golden.py: caesar_yolo/utils.py:622-697), incl. the three BASELINE grids."""
+    import json
+    from caesar_yolo_amd import utils
+    fx = json.load(open(os.path.join(golden_dir, "tiles.json")))
+    assert len(fx) >= 9
+    for name, case in fx.items():
+        got = utils.generate_tiles(*case["args"])
+        want = case["tiles"]
+        if want is None:
+            assert got is None, name
+        else:
+            assert got is not None and [list(t) for t in got] == [list(t) for t in want], name

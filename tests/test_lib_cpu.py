@@ -59,7 +59,7 @@ def _records_to_sources(rec, n, names):
     return out
 
 
-@pytest.mark.parametrize("tag", ["a", "b", "c"])
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
 def test_catalog_host_functions_against_reference_catalogs(golden_dir, tag):
     """cy_make_tile_records + cy_merge_edge_sources reproduce the reference's tiled catalog byte for byte when fed the
     per-tile merged detections (computed here by the oracle's process_detections on the recorded fake-model output)."""

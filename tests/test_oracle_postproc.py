@@ -62,7 +62,7 @@ def test_serial_catalog(golden_dir):
     assert saw["kw"]["imgsz"] == 640 and saw["kw"]["conf"] == 0.7 and saw["kw"]["iou"] == 0.5
 
 
-@pytest.mark.parametrize("tag", ["a", "b", "c"])
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
 def test_tiled_catalog(golden_dir, tag):
     fx = load(golden_dir, "catalog_tiled_%s.json" % tag)
     grid = [tuple(t) for t in fx["grid"]]

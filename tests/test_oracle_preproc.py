@@ -95,3 +95,28 @@ def test_row_check_quirk():
     img = np.random.default_rng(0).uniform(1, 2, (8, 8, 3))
     img[5] = 0.0          # only rows 0..2 are looked at
     assert not P.rows_constant(img)
+
+
+# ---- per-channel stage selection (--bkg_chid / --clip_chid; caesar_yolo/preprocessing.py:594-601 + :653, :667-672 + :712,
+# :726-732 + :766): tests/golden/preproc_chid.npz, captured from the imported reference by oracle/gen_golden.py
+CHID_SPECS = {
+    "bkg_chid0": [("bkg", dict(sigma=3, chid=0))],
+    "shiftclip_chid1_minmax": [("shift", dict(sigma=1, chid=1)), ("clip", dict(sigma_low=10, sigma_up=10, chid=1)),
+                               ("minmax", dict(norm_min=0, norm_max=255))],
+    "bkg_chid2_zscale_minmax": [("bkg", dict(sigma=3, chid=2)), ("zscale", dict(contrasts=[0.25] * 3)),
+                                ("minmax", dict(norm_min=0, norm_max=255))],
+    "bkgbox_chid1_clip_chid0": [("bkg", dict(sigma=3, use_mask_box=True, mask_fract=0.7, chid=1)),
+                                ("clip", dict(sigma_low=1, sigma_up=3, chid=0))],
+}
+
+
+@pytest.mark.parametrize("iname", ["galaxy", "syn192", "rag"])
+@pytest.mark.parametrize("pname", sorted(CHID_SPECS))
+def test_chid_stage_outputs(g, golden_dir, iname, pname):
+    gc = np.load(os.path.join(golden_dir, "preproc_chid.npz"))
+    res = P.build_pipeline(CHID_SPECS[pname])(P.to_cube(g["in/" + iname]))
+    ref = gc["out/%s/%s" % (iname, pname)]
+    assert res.shape == ref.shape and np.array_equal(res == 0, ref == 0)
+    close(res, ref)
+    if pname != "bkg_chid2_zscale_minmax":     # (a constant shift of one channel is normalised away again by zscale + minmax)
+        assert not np.array_equal(ref[:, :, 0], ref[:, :, 1]) or not np.array_equal(ref[:, :, 1], ref[:, :, 2])   # channels really differ
