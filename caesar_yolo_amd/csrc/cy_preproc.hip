@@ -14,16 +14,27 @@
 // non-finite".  The statistics kernel therefore never materialises intermediate images: a stage's input pixel is
 // recomputed from the raw fp32 pixel by replaying the already-solved maps in float64, operation for operation as numpy
 // does (contraction off), so thresholds see bit-identical values.  One 1024-thread workgroup owns one (tile, channel
-// program) and walks its stages; medians are exact (64-bit radix select, even counts average the two middle values).
+// program) and walks its stages.
+//
+// Medians are exact and cost three passes.  Every stage map is weakly monotone in its input (subtract / divide by a positive
+// constant / clamp / interpolate a cdf; a reversed MINMAX range in front of a sigma-clip stage is refused on the host), and a
+// pixel that hits 0 stays 0 and leaves every later set, so within a set the order of the replayed float64 values IS the
+// order of the raw fp32 pixels: the k-th smallest value is the replayed k-th smallest raw pixel, found by a radix select
+// over 32-bit keys (11 + 11 + 10 bits) instead of 64-bit ones.  The first level's histogram is filled by the same pass that
+// accumulates the set's count and moments, and an even count selects ranks n/2-1 and n/2 together (two prefixes, two
+// histograms), so one sigma-clip iteration is 3 passes over the tile where the first version of this kernel made 9.
 #include "cy_kernels.h"
 #include <math.h>
+#include <stddef.h>
 #pragma clang fp contract(off)
 
 namespace cy {
 
 constexpr int NT = 1024;            // threads per statistics workgroup
+constexpr int NWAVE = NT / 64;
 constexpr int PSTRIDE = MAX_STAGES * 4;
 constexpr int HEQ_STRIDE = 520;     // 256 centres + 256 cdf (+pad) doubles per (tile, channel)
+constexpr int PXU = 4;              // pixels per thread in flight in a pass
 
 __device__ __forceinline__ bool cond_of(double v) { return v != 0.0 && isfinite(v); }
 
@@ -41,10 +52,10 @@ __device__ __forceinline__ double interp256(double x, const double* xp, const do
 }
 
 // stage k applied to its input value v, with solved parameters sp[4]
-__device__ __forceinline__ double apply_stage(const PreStage& st, const double* sp, const double* heq, double v) {
+__device__ __forceinline__ double apply_stage(int op, double q0, double q1, const double* sp, const double* heq, double v) {
     const bool c = cond_of(v);
     double o = v;
-    switch (st.op) {
+    switch (op) {
         case OP_BKG: o = v - sp[0]; break;
         case OP_SHIFT: o = v - sp[0]; if (o < 0.0) o = 0.0; break;
         case OP_CLIP: if (o < sp[0]) o = sp[0]; if (o > sp[1]) o = sp[1]; break;
@@ -56,29 +67,31 @@ __device__ __forceinline__ double apply_stage(const PreStage& st, const double* 
             break;
         }
         case OP_HISTEQ: o = interp256(v, heq, heq + 256); break;
-        case OP_MINMAX: o = (v - sp[0]) / (sp[1] - sp[0]) * (st.p1 - st.p0) + st.p0; break;
+        case OP_MINMAX: o = (v - sp[0]) / (sp[1] - sp[0]) * (q1 - q0) + q0; break;
         default: break;
     }
     return c ? o : 0.0;
 }
 
-__device__ __forceinline__ double chain_value(const PreProgram& pg, int upto, const double* params, const double* heq, double raw) {
-    double v = raw;
-    for (int k = 0; k < upto; ++k) v = apply_stage(pg.st[k], params + k * 4, heq, v);
-    return v;
-}
-
-// ---------------------------------------------------------------------------------------- block primitives
+// ---------------------------------------------------------------------------------------- block state
 struct Smem {
-    double red[32];
-    unsigned hist[2048];
-    unsigned scan[NT];
+    double red[3 * NWAVE];
+    unsigned histA[2048], histB[2048];
+    unsigned scan[NT], scan2[NT];
     double zs[1024];
     unsigned char bad[1024], bad2[1024];
-    double bc[8];
+    double heq[512];                     // HISTEQ tables of this (tile, channel), once solved
+    int op[MAX_STAGES], flag[MAX_STAGES]; // this channel's program ...
+    double q0[MAX_STAGES], q1[MAX_STAGES];
+    double par[MAX_STAGES * 4];          // ... and the parameters solved so far
     unsigned long long bcu[4];
-    int bci[4];
 };
+
+__device__ __forceinline__ double chain_value(const Smem& s, int upto, double raw) {
+    double v = raw;
+    for (int k = 0; k < upto; ++k) v = apply_stage(s.op[k], s.q0[k], s.q1[k], s.par + k * 4, s.heq, v);
+    return v;
+}
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -96,14 +109,14 @@ __device__ __forceinline__ double wave_max(double v) {
     return v;
 }
 // all threads get the result; fixed tree => run-to-run deterministic
-template <int MODE> __device__ double block_reduce(Smem& s, double v) {
+template <int MODE> __device__ __forceinline__ double block_reduce(Smem& s, double v) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     v = MODE == 0 ? wave_sum(v) : (MODE == 1 ? wave_min(v) : wave_max(v));
     __syncthreads();
     if (lane == 0) s.red[w] = v;
     __syncthreads();
     if (w == 0) {
-        double x = lane < NT / 64 ? s.red[lane] : (MODE == 0 ? 0.0 : (MODE == 1 ? INFINITY : -INFINITY));
+        double x = lane < NWAVE ? s.red[lane] : (MODE == 0 ? 0.0 : (MODE == 1 ? INFINITY : -INFINITY));
         x = MODE == 0 ? wave_sum(x) : (MODE == 1 ? wave_min(x) : wave_max(x));
         if (lane == 0) s.red[0] = x;
     }
@@ -115,14 +128,29 @@ template <int MODE> __device__ double block_reduce(Smem& s, double v) {
 __device__ __forceinline__ double block_sum(Smem& s, double v) { return block_reduce<0>(s, v); }
 __device__ __forceinline__ double block_min(Smem& s, double v) { return block_reduce<1>(s, v); }
 __device__ __forceinline__ double block_max(Smem& s, double v) { return block_reduce<2>(s, v); }
-
-__device__ __forceinline__ unsigned long long dkey(double v) {          // order-preserving double -> u64
-    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+// three sums with one pair of barriers
+__device__ __forceinline__ void block_sum3(Smem& s, double& a, double& b, double& c) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+    __syncthreads();
+    if (lane == 0) { s.red[w] = a; s.red[NWAVE + w] = b; s.red[2 * NWAVE + w] = c; }
+    __syncthreads();
+    if (w == 0) {
+        double x = lane < NWAVE ? s.red[lane] : 0.0, y = lane < NWAVE ? s.red[NWAVE + lane] : 0.0, z = lane < NWAVE ? s.red[2 * NWAVE + lane] : 0.0;
+        x = wave_sum(x); y = wave_sum(y); z = wave_sum(z);
+        if (lane == 0) { s.red[0] = x; s.red[NWAVE] = y; s.red[2 * NWAVE] = z; }
+    }
+    __syncthreads();
+    a = s.red[0]; b = s.red[NWAVE]; c = s.red[2 * NWAVE];
+    __syncthreads();
 }
-__device__ __forceinline__ double dkey_inv(unsigned long long k) {
-    const unsigned long long b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
-    return __longlong_as_double((long long)b);
+
+__device__ __forceinline__ unsigned fkey(float f) {                     // order-preserving float -> u32
+    const unsigned b = __float_as_uint(f);
+    return (b >> 31) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(unsigned k) {
+    return __uint_as_float((k >> 31) ? (k & 0x7FFFFFFFu) : ~k);
 }
 
 struct TileView {
@@ -130,41 +158,45 @@ struct TileView {
     __device__ __forceinline__ double raw(int i) const { const int y = i / tw, x = i - y * tw; return (double)base[(size_t)y * MW + x]; }
 };
 
-// One pass over the tile, four pixels per thread in flight.  Every statistics pass re-reads the raw tile (1-1.6 MB per
-// workgroup, dozens of passes for a sigma-clip stage), and with one dependent load per thread and iteration the passes ran
-// at ~2 TB/s chip-wide, latency-bound; batching the loads keeps each thread's pixel ORDER (i = tid, tid+NT, ...), so sums
-// are bit-identical.  f(i, raw, ok) is called by every lane of the workgroup (ok = false past the end): it may ballot.
+// membership of a pixel in the current sigma-clip set
+struct ClipSet { double L, U; int use_box, bx0, bx1, by0, by1; };
+
+// One pass over the tile, PXU pixels per thread in flight (every statistics pass re-reads the raw tile, 1-1.6 MB per
+// workgroup; with one dependent load per thread the passes were latency-bound).  The replayed values of a batch are computed
+// before any of them is consumed, so the program / parameter reads from LDS are shared by the batch.
+// f(raw fp32, value, in_box, ok) is called by every lane of the workgroup (ok = false past the end): it may ballot.
 template <typename F>
-__device__ __forceinline__ void for_pixels(const TileView& tv, F&& f) {
+__device__ __forceinline__ void for_pixels(const Smem& s, const TileView& tv, int upto, const ClipSet* box, F&& f) {
     // (y, x) of the thread's next pixel, advanced by NT pixels per load: one integer division per pass, not per pixel
     int y = (int)threadIdx.x / tv.tw, x = (int)threadIdx.x - y * tv.tw;
     const int dy = NT / tv.tw, dx = NT - dy * tv.tw;
-    for (int i0 = 0; i0 < tv.npix; i0 += 4 * NT) {
-        double r[4];
-        bool ok[4];
+    const bool use_box = box && box->use_box;
+    for (int i0 = 0; i0 < tv.npix; i0 += PXU * NT) {
+        float r[PXU];
+        bool ok[PXU], inb[PXU];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < PXU; ++u) {
             const int i = i0 + u * NT + (int)threadIdx.x;
             ok[u] = i < tv.npix;
-            r[u] = ok[u] ? (double)tv.base[(size_t)y * tv.MW + x] : 0.0;
+            r[u] = ok[u] ? tv.base[(size_t)y * tv.MW + x] : 0.0f;
+            inb[u] = use_box && y >= box->by0 && y < box->by1 && x >= box->bx0 && x < box->bx1;
             x += dx; y += dy;
             if (x >= tv.tw) { x -= tv.tw; ++y; }
         }
+        double v[PXU];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) f(i0 + u * NT + (int)threadIdx.x, r[u], ok[u]);
+        for (int u = 0; u < PXU; ++u) v[u] = chain_value(s, upto, (double)r[u]);
+#pragma unroll
+        for (int u = 0; u < PXU; ++u) f(r[u], v[u], inb[u], ok[u]);
     }
 }
 
-// membership of pixel value v in the current sigma-clip set
-struct ClipSet { double L, U; int use_box, bx0, bx1, by0, by1; };
-__device__ __forceinline__ bool in_set(const ClipSet& cs, const TileView& tv, int i, double v) {
-    if (!cond_of(v)) return false;
-    if (cs.use_box) { const int y = i / tv.tw, x = i - y * tv.tw; if (y >= cs.by0 && y < cs.by1 && x >= cs.bx0 && x < cs.bx1) return false; }
-    return v >= cs.L && v <= cs.U;
+__device__ __forceinline__ bool in_set(const ClipSet& cs, double v, bool in_box) {
+    return cond_of(v) && !in_box && v >= cs.L && v <= cs.U;
 }
 
 // Histogram increment with wave-level aggregation.  Radio-map pixels are mostly background noise of one sign and exponent,
-// so in the leading radix passes (and in the 256-bin equalisation histogram) almost every lane of a wave hits the SAME bin:
+// so in the leading radix level (and in the 256-bin equalisation histogram) almost every lane of a wave hits the SAME bin:
 // plain LDS atomics serialise on that address (measured: 13 ms per 96-tile batch of the 3-channel 640^2 pipeline).  Up to
 // three rounds of "count the lanes that share the first pending lane's bin, one atomic for all of them" take care of the
 // concentrated case; whatever is still pending afterwards (uniformly spread low bits) goes through ordinary atomics.
@@ -183,81 +215,104 @@ __device__ __forceinline__ void hist_add(unsigned* hist, unsigned bin, bool acti
     if (active) atomicAdd(&hist[bin], 1u);
 }
 
-// exact k-th smallest (0-based) of the set, as a key; 6 passes of 11/11/11/11/11/9 bits
-__device__ unsigned long long radix_select(Smem& s, const TileView& tv, const PreProgram& pg, int upto, const double* params,
-                                           const double* heq, const ClipSet& cs, unsigned long long k) {
-    unsigned long long prefix = 0ull, pmask = 0ull;
-    const int shifts[6] = {53, 42, 31, 20, 9, 0};
-    const int bits[6] = {11, 11, 11, 11, 11, 9};
-    for (int p = 0; p < 6; ++p) {
-        const int nb = 1 << bits[p];
-        for (int i = threadIdx.x; i < nb; i += NT) s.hist[i] = 0u;
+// buckets of ranks kA and kB (0-based) in histograms hA / hB (the same array when both ranks share a prefix) of nb <= 2048 bins:
+// -> bins, and the counts of elements in lower bins
+__device__ __forceinline__ void locate2(Smem& s, const unsigned* hA, const unsigned* hB, int nb, unsigned long long kA, unsigned long long kB,
+                                        unsigned* binA, unsigned long long* befA, unsigned* binB, unsigned long long* befB) {
+    const int t = threadIdx.x;
+    const unsigned a0 = (2 * t < nb) ? hA[2 * t] : 0u, a1 = (2 * t + 1 < nb) ? hA[2 * t + 1] : 0u;
+    const unsigned b0 = (2 * t < nb) ? hB[2 * t] : 0u, b1 = (2 * t + 1 < nb) ? hB[2 * t + 1] : 0u;
+    s.scan[t] = a0 + a1; s.scan2[t] = b0 + b1;
+    __syncthreads();
+    for (int off = 1; off < NT; off <<= 1) {
+        const unsigned addA = t >= off ? s.scan[t - off] : 0u, addB = t >= off ? s.scan2[t - off] : 0u;
         __syncthreads();
-        for_pixels(tv, [&](int i, double rv, bool act) {      // whole waves stay in the pass: hist_add uses ballots
-            unsigned bin = 0u;
-            if (act) {
-                const double v = chain_value(pg, upto, params, heq, rv);
-                act = in_set(cs, tv, i, v);
-                if (act) {
-                    const unsigned long long key = dkey(v);
-                    act = (key & pmask) == prefix;
-                    bin = (unsigned)((key >> shifts[p]) & (unsigned long long)(nb - 1));
-                }
-            }
-            hist_add(s.hist, bin, act);
-        });
-        __syncthreads();
-        // locate the bucket holding rank k: thread t owns bins 2t, 2t+1; exclusive scan of the pair sums
-        const int t = threadIdx.x;
-        const unsigned h0 = (2 * t < nb) ? s.hist[2 * t] : 0u, h1 = (2 * t + 1 < nb) ? s.hist[2 * t + 1] : 0u;
-        s.scan[t] = h0 + h1;
-        __syncthreads();
-        for (int off = 1; off < NT; off <<= 1) {
-            const unsigned add = t >= off ? s.scan[t - off] : 0u;
-            __syncthreads();
-            s.scan[t] += add;
-            __syncthreads();
-        }
-        const unsigned long long incl = s.scan[t], excl = incl - (h0 + h1);
-        if (k >= excl && k < incl) {
-            int bin; unsigned long long before;
-            if (k < excl + h0) { bin = 2 * t; before = excl; } else { bin = 2 * t + 1; before = excl + h0; }
-            s.bcu[0] = (unsigned long long)bin; s.bcu[1] = before;
-        }
-        __syncthreads();
-        prefix |= s.bcu[0] << shifts[p];
-        pmask |= (unsigned long long)(nb - 1) << shifts[p];
-        k -= s.bcu[1];
+        s.scan[t] += addA; s.scan2[t] += addB;
         __syncthreads();
     }
-    return prefix;
+    const unsigned long long inclA = s.scan[t], exclA = inclA - (a0 + a1);
+    const unsigned long long inclB = s.scan2[t], exclB = inclB - (b0 + b1);
+    if (kA >= exclA && kA < inclA) {
+        if (kA < exclA + a0) { s.bcu[0] = (unsigned long long)(2 * t); s.bcu[1] = exclA; }
+        else { s.bcu[0] = (unsigned long long)(2 * t + 1); s.bcu[1] = exclA + a0; }
+    }
+    if (kB >= exclB && kB < inclB) {
+        if (kB < exclB + b0) { s.bcu[2] = (unsigned long long)(2 * t); s.bcu[3] = exclB; }
+        else { s.bcu[2] = (unsigned long long)(2 * t + 1); s.bcu[3] = exclB + b0; }
+    }
+    __syncthreads();
+    *binA = (unsigned)s.bcu[0]; *befA = s.bcu[1]; *binB = (unsigned)s.bcu[2]; *befB = s.bcu[3];
+    __syncthreads();
+}
+
+__device__ __forceinline__ void clear_hists(Smem& s, bool both) {
+    for (int i = threadIdx.x; i < 2048; i += NT) { s.histA[i] = 0u; if (both) s.histB[i] = 0u; }
+}
+
+// Median of the set (n >= 1 members) given the level-0 histogram of its raw keys in s.histA (top 11 bits): two more passes.
+__device__ __forceinline__ double set_median(Smem& s, const TileView& tv, int upto, const ClipSet& cs, unsigned long long n) {
+    unsigned long long kA = (n - 1) / 2, kB = n / 2;                 // equal for odd n
+    unsigned pA = 0u, pB = 0u, pmask = 0u;
+#pragma unroll 1
+    for (int lvl = 0; lvl < 3; ++lvl) {
+        const int shift = lvl == 0 ? 21 : (lvl == 1 ? 10 : 0), nbits = lvl == 2 ? 10 : 11;
+        const unsigned nbm = (1u << nbits) - 1u;
+        const bool two = pA != pB;
+        if (lvl > 0) {                                               // level 0 was filled by set_moments
+            __syncthreads();
+            clear_hists(s, two);
+            __syncthreads();
+            for_pixels(s, tv, upto, &cs, [&](float rf, double v, bool inb, bool act) {
+                act = act && in_set(cs, v, inb);
+                const unsigned key = fkey(rf);
+                const unsigned bin = (key >> shift) & nbm;
+                hist_add(s.histA, bin, act && (key & pmask) == pA);
+                if (two) hist_add(s.histB, bin, act && (key & pmask) == pB);
+            });
+            __syncthreads();
+        }
+        unsigned binA, binB; unsigned long long befA, befB;
+        locate2(s, s.histA, two ? s.histB : s.histA, 1 << nbits, kA, kB, &binA, &befA, &binB, &befB);
+        pA |= binA << shift; pB |= binB << shift;
+        kA -= befA; kB -= befB;
+        pmask |= nbm << shift;
+    }
+    const double a = chain_value(s, upto, (double)fkey_inv(pA));
+    if (pA == pB) return a;
+    const double b = chain_value(s, upto, (double)fkey_inv(pB));
+    return 0.5 * (a + b);
 }
 
 struct ClipStats { double lo, hi, mean, median, std; unsigned long long n; };
 
-__device__ double set_median(Smem& s, const TileView& tv, const PreProgram& pg, int upto, const double* params, const double* heq,
-                             const ClipSet& cs, unsigned long long n) {
-    const unsigned long long k1 = (n - 1) / 2;
-    const unsigned long long ka = radix_select(s, tv, pg, upto, params, heq, cs, k1);
-    const double a = dkey_inv(ka);
-    if (n & 1ull) return a;
-    // even count: the upper middle is `a` again if duplicates cover rank n/2, else the smallest value above `a`
-    double cle = 0.0, nxt = INFINITY;
-    for_pixels(tv, [&](int i, double rv, bool ok) {
-        if (!ok) return;
-        const double v = chain_value(pg, upto, params, heq, rv);
-        if (!in_set(cs, tv, i, v)) return;
-        if (v <= a) cle += 1.0; else nxt = fmin(nxt, v);
+// count and the moments about K of the current set, plus the level-0 radix histogram of its raw keys (s.histA)
+__device__ __forceinline__ void set_moments(Smem& s, const TileView& tv, int upto, const ClipSet& cs, double K,
+                                            unsigned long long* n_out, double* mean_out, double* std_out) {
+    __syncthreads();
+    clear_hists(s, false);
+    __syncthreads();
+    double cnt = 0.0, s1 = 0.0, s2 = 0.0;
+    for_pixels(s, tv, upto, &cs, [&](float rf, double v, bool inb, bool act) {
+        act = act && in_set(cs, v, inb);
+        if (act) { const double d = v - K; cnt += 1.0; s1 += d; s2 += d * d; }
+        hist_add(s.histA, fkey(rf) >> 21, act);
     });
-    cle = block_sum(s, cle);
-    nxt = block_min(s, nxt);
-    const double b = (cle >= (double)(n / 2 + 1)) ? a : nxt;
-    return 0.5 * (a + b);
+    block_sum3(s, cnt, s1, s2);
+    const unsigned long long n = (unsigned long long)cnt;
+    *n_out = n;
+    if (n) {
+        const double m1 = s1 / cnt;                       // mean - K
+        double var = s2 / cnt - m1 * m1;
+        if (var < 0.0) var = 0.0;
+        *mean_out = K + m1; *std_out = sqrt(var);
+    } else { *mean_out = NAN; *std_out = NAN; }
 }
 
 // astropy SigmaClip._sigmaclip_noaxis (maxiters 5, median centre, std spread) + statistics of the survivors
-__device__ ClipStats sigma_clip_run(Smem& s, const TileView& tv, const PreProgram& pg, int upto, const double* params, const double* heq,
-                                    double slo, double sup, int use_box, double mask_fract) {
+// (sigma_clipped_stats).  One loop, one moments pass and one median per trip: the set's count, its moments about K and the
+// first radix level come out of ONE pass; K is the previous median (for the initial set: a first trip about 0 finds the
+// median, a second one accumulates about it), so var = E[d^2] - E[d]^2 loses nothing against numpy's two-pass form.
+__device__ __forceinline__ ClipStats sigma_clip_run(Smem& s, const TileView& tv, int upto, double slo, double sup, int use_box, double mask_fract) {
     ClipSet cs{-INFINITY, INFINITY, use_box, 0, 0, 0, 0};
     if (use_box) {
         const int xc = tv.tw / 2, yc = tv.th / 2;
@@ -267,65 +322,33 @@ __device__ ClipStats sigma_clip_run(Smem& s, const TileView& tv, const PreProgra
         if (cs.by0 < 0) cs.by0 = 0;
     }
     ClipStats r{NAN, NAN, NAN, NAN, NAN, 0ull};
-    double cnt = 0.0, sum = 0.0;
-    for_pixels(tv, [&](int i, double rv, bool ok) {
-        if (!ok) return;
-        const double v = chain_value(pg, upto, params, heq, rv);
-        if (in_set(cs, tv, i, v)) { cnt += 1.0; sum += v; }
-    });
-    cnt = block_sum(s, cnt); sum = block_sum(s, sum);
-    unsigned long long n = (unsigned long long)cnt;
-    bool fresh = false;                      // are mean/median/std valid for the CURRENT set?
-    for (int it = 0; it < 5 && n > 0; ++it) {
-        const double mean = sum / (double)n;
-        double ssq = 0.0;
-        for_pixels(tv, [&](int i, double rv, bool ok) {
-            if (!ok) return;
-            const double v = chain_value(pg, upto, params, heq, rv);
-            if (in_set(cs, tv, i, v)) { const double d = v - mean; ssq += d * d; }
-        });
-        ssq = block_sum(s, ssq);
-        const double sd = sqrt(ssq / (double)n);
-        const double med = set_median(s, tv, pg, upto, params, heq, cs, n);
-        r.mean = mean; r.median = med; r.std = sd; r.n = n;
+    unsigned long long n = 0, nprev = ~0ull;
+    double mean = NAN, sd = NAN, med = NAN, K = 0.0;
+    int c = -2;                               // -2: first trip (about 0), -1: initial set about its median, >= 0: clips done
+#pragma unroll 1
+    for (;;) {
+        set_moments(s, tv, upto, cs, K, &n, &mean, &sd);
+        if (c >= 1 && n == nprev) break;      // the clip removed nothing: converged, (mean, sd, med) describe this very set
+        if (n == 0) { mean = sd = med = NAN; break; }
+        if (c != -1) med = set_median(s, tv, upto, cs, n);
+        if (c == -2) { K = med; c = -1; continue; }
+        if (c == -1) c = 0;
+        if (c == 5) break;                    // maxiters: statistics of the final survivors, bounds of the fifth iteration
         r.lo = med - sd * slo; r.hi = med + sd * sup;
         cs.L = fmax(cs.L, r.lo); cs.U = fmin(cs.U, r.hi);
-        double c2 = 0.0, s2 = 0.0;
-        for_pixels(tv, [&](int i, double rv, bool ok) {
-            if (!ok) return;
-            const double v = chain_value(pg, upto, params, heq, rv);
-            if (in_set(cs, tv, i, v)) { c2 += 1.0; s2 += v; }
-        });
-        c2 = block_sum(s, c2); s2 = block_sum(s, s2);
-        const unsigned long long n2 = (unsigned long long)c2;
-        const bool changed = n2 != n;
-        n = n2; sum = s2;
-        fresh = !changed;
-        if (!changed) break;
+        nprev = n; K = med; ++c;
     }
-    if (!fresh && n > 0) {                   // stopped by maxiters: statistics of the final survivors
-        const double mean = sum / (double)n;
-        double ssq = 0.0;
-        for_pixels(tv, [&](int i, double rv, bool ok) {
-            if (!ok) return;
-            const double v = chain_value(pg, upto, params, heq, rv);
-            if (in_set(cs, tv, i, v)) { const double d = v - mean; ssq += d * d; }
-        });
-        ssq = block_sum(s, ssq);
-        r.mean = mean; r.std = sqrt(ssq / (double)n); r.median = set_median(s, tv, pg, upto, params, heq, cs, n); r.n = n;
-    }
-    if (n == 0) r.n = 0;
+    r.mean = mean; r.median = med; r.std = sd; r.n = n;
     return r;
 }
 
 // astropy ZScaleInterval.get_limits (nsamples 1000, max_reject 0.5, min_npixels 5, krej 2.5, max_iterations 5)
-__device__ void zscale_run(Smem& s, const TileView& tv, const PreProgram& pg, int upto, const double* params, const double* heq,
-                           double contrast, double* vmin_out, double* vmax_out) {
+__device__ __forceinline__ void zscale_run(Smem& s, const TileView& tv, int upto, double contrast, double* vmin_out, double* vmax_out) {
     const int t = threadIdx.x;
     int stride = (int)fmax(1.0, (double)tv.npix / 1000.0);
     int ns = (tv.npix + stride - 1) / stride;
     if (ns > 1000) ns = 1000;
-    s.zs[t] = t < ns ? chain_value(pg, upto, params, heq, tv.raw(t * stride)) : INFINITY;
+    s.zs[t] = t < ns ? chain_value(s, upto, tv.raw(t * stride)) : INFINITY;
     __syncthreads();
     for (int kk = 2; kk <= 1024; kk <<= 1)
         for (int j = kk >> 1; j > 0; j >>= 1) {
@@ -350,9 +373,11 @@ __device__ void zscale_run(Smem& s, const TileView& tv, const PreProgram& pg, in
         if (ngood >= last || ngood < minpix) break;
         const double w = (t < npix && !s.bad[t]) ? 1.0 : 0.0;
         // weighted straight-line least squares (np.polyfit deg 1, w in {0,1}) in centred form
-        const double sw = block_sum(s, w), sx = block_sum(s, w * x), sy = block_sum(s, w * y);
+        double sw = w, sx = w * x, sy = w * y;
+        block_sum3(s, sw, sx, sy);
         const double xm = sx / sw, ym = sy / sw;
-        const double sxx = block_sum(s, w * (x - xm) * (x - xm)), sxy = block_sum(s, w * (x - xm) * (y - ym));
+        double sxx = w * (x - xm) * (x - xm), sxy = w * (x - xm) * (y - ym), zero = 0.0;
+        block_sum3(s, sxx, sxy, zero);
         slope = sxy / sxx;
         const double icpt = ym - slope * xm;
         const double flat = y - (slope * x + icpt);
@@ -390,24 +415,22 @@ __device__ void zscale_run(Smem& s, const TileView& tv, const PreProgram& pg, in
 }
 
 // skimage equalize_hist tables: np.histogram(image, 256) over [min,max] (zeros included), cdf, bin centres
-__device__ void histeq_run(Smem& s, const TileView& tv, const PreProgram& pg, int upto, const double* params, double* heq) {
+__device__ __forceinline__ void histeq_run(Smem& s, const TileView& tv, int upto, double* heq_global) {
     double mn = INFINITY, mx = -INFINITY;
-    for_pixels(tv, [&](int i, double rv, bool ok) {
-        if (!ok) return;
-        const double v = chain_value(pg, upto, params, heq, rv);
-        mn = fmin(mn, v); mx = fmax(mx, v);
+    for_pixels(s, tv, upto, nullptr, [&](float, double v, bool, bool ok) {
+        if (ok) { mn = fmin(mn, v); mx = fmax(mx, v); }
     });
     mn = block_min(s, mn); mx = block_max(s, mx);
     double first = mn, last = mx;
     if (first == last) { first -= 0.5; last += 0.5; }
     const double step = (last - first) / 256.0;
     auto edge = [&](int i) { return i == 256 ? last : (double)i * step + first; };       // np.linspace
-    for (int i = threadIdx.x; i < 256; i += NT) s.hist[i] = 0u;
     __syncthreads();
-    for_pixels(tv, [&](int i, double rv, bool act) {
+    clear_hists(s, false);
+    __syncthreads();
+    for_pixels(s, tv, upto, nullptr, [&](float, double v, bool, bool act) {
         int idx = 0;
         if (act) {
-            const double v = chain_value(pg, upto, params, heq, rv);
             idx = (int)(((v - first) / (last - first)) * 256.0);
             if (idx == 256) idx = 255;
             if (idx < 0) idx = 0;
@@ -415,66 +438,90 @@ __device__ void histeq_run(Smem& s, const TileView& tv, const PreProgram& pg, in
             if (v < edge(idx)) idx -= 1;
             else if (v >= edge(idx + 1) && idx != 255) idx += 1;
         }
-        hist_add(s.hist, (unsigned)idx, act);
+        hist_add(s.histA, (unsigned)idx, act);
     });
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned long long c = 0ull;
-        for (int i = 0; i < 256; ++i) { c += s.hist[i]; s.zs[i] = (double)c; }
+        for (int i = 0; i < 256; ++i) { c += s.histA[i]; s.zs[i] = (double)c; }
         for (int i = 0; i < 256; ++i) {
-            heq[256 + i] = s.zs[i] / (double)c;
-            heq[i] = (edge(i) + edge(i + 1)) / 2.0;
+            s.heq[256 + i] = s.zs[i] / (double)c;
+            s.heq[i] = (edge(i) + edge(i + 1)) / 2.0;
         }
     }
-    __threadfence_block();
+    __syncthreads();
+    for (int i = threadIdx.x; i < 512; i += NT) heq_global[i] = s.heq[i];
     __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------- statistics kernel
+// The argument block is read through scalar fields and two copies into LDS only (the channel's program, the tile origin):
+// handing `a.prog[p]` to the routines above by reference made the compiler keep a private copy of the whole 3.3 KB block in
+// scratch memory (ScratchSize 3352 B per lane, ~570 MB of scratch writes per launch) and read every stage from there per pixel.
 __global__ __launch_bounds__(NT) void pre_stats_kernel(const PreArgs a) {
     __shared__ Smem s;
     const int b = blockIdx.x, p = blockIdx.y;
-    const PreProgram& pg = a.prog[p];
+    // dynamically indexed members (prog[p].st[k], txy[2b]) are read straight from the kernel-argument segment
+    typedef const __attribute__((address_space(4))) char* kptr;
+    const kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    const kptr kprog = ka + offsetof(PreArgs, prog) + (size_t)p * sizeof(PreProgram);
+    auto kint = [](kptr q) { return *(const __attribute__((address_space(4))) int*)q; };
+    auto kdbl = [](kptr q) { return *(const __attribute__((address_space(4))) double*)q; };
+    const int nst = kint(kprog + offsetof(PreProgram, n));
+    if (threadIdx.x < MAX_STAGES) {
+        const int k = threadIdx.x;
+        const kptr ks = kprog + offsetof(PreProgram, st) + (size_t)k * sizeof(PreStage);
+        s.op[k] = k < nst ? kint(ks + offsetof(PreStage, op)) : 0;
+        s.q0[k] = kdbl(ks + offsetof(PreStage, p0)); s.q1[k] = kdbl(ks + offsetof(PreStage, p1));
+        s.flag[k] = kint(ks + offsetof(PreStage, flag));
+    }
+    const int tx0 = kint(ka + offsetof(PreArgs, txy) + (size_t)(2 * b) * 4), ty0 = kint(ka + offsetof(PreArgs, txy) + (size_t)(2 * b + 1) * 4);
     double* params = a.params + ((size_t)b * 3 + p) * PSTRIDE;
     double* heq = a.histeq + ((size_t)b * 3 + p) * HEQ_STRIDE;
-    TileView tv{a.mosaic + (size_t)a.txy[2 * b + 1] * a.MW + a.txy[2 * b], a.MW, a.tw, a.th, a.tw * a.th};
+    TileView tv{a.mosaic + (size_t)ty0 * a.MW + tx0, a.MW, a.tw, a.th, a.tw * a.th};
+    __syncthreads();
     int status = 0;
-    for (int k = 0; k < pg.n; ++k) {
-        const PreStage& st = pg.st[k];
+    for (int k = 0; k < nst; ++k) {
+        const int op = s.op[k];
+        const double p0 = s.q0[k], p1 = s.q1[k];
+        const int flag = s.flag[k];
         double o0 = 0, o1 = 0, o2 = 0, o3 = 0;
-        if (st.op == OP_BKG) {
-            const ClipStats r = sigma_clip_run(s, tv, pg, k, params, heq, st.p0, st.p0, st.flag, st.p1);
-            o0 = r.mean; if (r.n == 0) status = 1;
-        } else if (st.op == OP_SHIFT) {
-            const ClipStats r = sigma_clip_run(s, tv, pg, k, params, heq, st.p0, st.p0, 0, 0.0);
-            o0 = r.mean + st.p0 * r.std; o1 = r.mean; o2 = r.std; if (r.n == 0) status = 1;
-        } else if (st.op == OP_CLIP) {
+        if (op == OP_BKG || op == OP_SHIFT || op == OP_CLIP) {
             // astropy: `sigma_lower or sigma` -- a 0 falls back to the default sigma = 3
-            const double slo = st.p0 != 0.0 ? st.p0 : 3.0, sup = st.p1 != 0.0 ? st.p1 : 3.0;
-            const ClipStats r = sigma_clip_run(s, tv, pg, k, params, heq, slo, sup, 0, 0.0);
-            o0 = r.lo; o1 = r.hi; if (r.n == 0 && isnan(r.lo)) status = 1;
-        } else if (st.op == OP_ZSCALE) {
-            zscale_run(s, tv, pg, k, params, heq, st.p0, &o0, &o1);
-        } else if (st.op == OP_HISTEQ) {
-            histeq_run(s, tv, pg, k, params, heq);
-        } else if (st.op == OP_MINMAX) {
+            const double slo = op == OP_CLIP ? (p0 != 0.0 ? p0 : 3.0) : p0, sup = op == OP_CLIP ? (p1 != 0.0 ? p1 : 3.0) : p0;
+            const ClipStats r = sigma_clip_run(s, tv, k, slo, sup, op == OP_BKG ? flag : 0, op == OP_BKG ? p1 : 0.0);
+            if (op == OP_BKG) { o0 = r.mean; if (r.n == 0) status = 1; }
+            else if (op == OP_SHIFT) { o0 = r.mean + p0 * r.std; o1 = r.mean; o2 = r.std; if (r.n == 0) status = 1; }
+            else { o0 = r.lo; o1 = r.hi; if (r.n == 0 && isnan(r.lo)) status = 1; }
+        } else if (op == OP_ZSCALE) {
+            zscale_run(s, tv, k, p0, &o0, &o1);
+        } else if (op == OP_HISTEQ) {
+            histeq_run(s, tv, k, heq);
+        } else if (op == OP_MINMAX) {
             double mn = INFINITY, mx = -INFINITY;
-            for (int i = threadIdx.x; i < tv.npix; i += NT) {
-                const double v = chain_value(pg, k, params, heq, tv.raw(i));
-                if (cond_of(v)) { mn = fmin(mn, v); mx = fmax(mx, v); }
-            }
-            o0 = block_min(s, mn); o1 = block_max(s, mx); o2 = st.p0; o3 = st.p1;
+            for_pixels(s, tv, k, nullptr, [&](float, double v, bool, bool ok) {
+                if (ok && cond_of(v)) { mn = fmin(mn, v); mx = fmax(mx, v); }
+            });
+            o0 = block_min(s, mn); o1 = block_max(s, mx); o2 = p0; o3 = p1;
             if (!(o0 <= o1)) status = 1;           // no non-zero finite pixel: the stage returns None (preprocessing.py:101-103)
         }
         __syncthreads();
-        if (threadIdx.x == 0) { params[k * 4] = o0; params[k * 4 + 1] = o1; params[k * 4 + 2] = o2; params[k * 4 + 3] = o3; }
-        __threadfence_block();
+        if (threadIdx.x == 0) {
+            params[k * 4] = o0; params[k * 4 + 1] = o1; params[k * 4 + 2] = o2; params[k * 4 + 3] = o3;
+            s.par[k * 4] = o0; s.par[k * 4 + 1] = o1; s.par[k * 4 + 2] = o2; s.par[k * 4 + 3] = o3;
+        }
         __syncthreads();
     }
     if (threadIdx.x == 0 && status) atomicMax(a.status + b, status);
 }
 
 // ---------------------------------------------------------------------------------------- apply + letterbox + pack
+__device__ __forceinline__ double chain_value(const PreProgram& pg, int upto, const double* params, const double* heq, double raw) {
+    double v = raw;
+    for (int k = 0; k < upto; ++k) v = apply_stage(pg.st[k].op, pg.st[k].p0, pg.st[k].p1, params + k * 4, heq, v);
+    return v;
+}
+
 __device__ __forceinline__ void tile_channels(const PreArgs& a, int b, double raw, double out[3]) {
     if (a.nprog == 0) { out[0] = out[1] = out[2] = raw; return; }
     for (int c = 0; c < 3; ++c) {

@@ -762,8 +762,15 @@ int cy_preproc(cy_ctx* c, const float* d_mosaic, int MH, int MW, const int* h_ti
     for (int i = 0; i < 3; ++i) {
         a.prog[i].n = cfg->prog[i].n;
         if (a.prog[i].n < 0 || a.prog[i].n > MAX_STAGES) return fail(c, CY_ERR_ARG, "too many stages");
+        bool reversed = false;               // a decreasing map so far (MINMAX with norm_max < norm_min)
         for (int j = 0; j < a.prog[i].n; ++j) {
             const cy_pre_stage& st = cfg->prog[i].st[j];
+            if (st.op < CY_OP_BKG || st.op > CY_OP_MINMAX) return fail(c, CY_ERR_ARG, "unknown preprocessing op");
+            // the statistics kernel selects medians by the order of the RAW pixels, which needs every earlier map to be
+            // non-decreasing (cy_preproc.hip); the CLI order (scripts/run.py:272-302) puts MINMAX last, so this never fires there
+            if (reversed && (st.op == CY_OP_BKG || st.op == CY_OP_SHIFT || st.op == CY_OP_CLIP))
+                return fail(c, CY_ERR_UNSUPPORTED, "a sigma-clip stage after a MINMAX stage with norm_max < norm_min is not supported");
+            if (st.op == CY_OP_MINMAX && st.p1 < st.p0) reversed = !reversed;
             a.prog[i].st[j] = PreStage{st.op, st.p0, st.p1, st.p2, st.flag};
         }
     }

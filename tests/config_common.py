@@ -125,29 +125,34 @@ def sources_as_sets(src):
     return b, np.array([s["score"] for s in src], np.float64), np.array([s["class_id"] for s in src], np.int64)
 
 
-def nms_level_report(got, ref):
+def nms_level_report(got, ref, H=0, W=0):
     """Kept-box sets after NMS compared by ANCHOR INDEX (the north star's "kept-box index set"): got / ref =
-    (boxes, scores, classes, anchors).  -> dict(ref, got, common, max_dbox, max_dscore over the common anchors)."""
+    (boxes, scores, classes, anchors); H, W = letterboxed network input (anchor -> stride).
+    -> dict(ref, got, common, max_dbox [px], max_dbox_strides [box delta / the anchor's stride], max_dscore over the common anchors)."""
     gb, gs, gc, ga = (np.asarray(x) for x in got)
     rb, rs, rc, ra = (np.asarray(x) for x in ref)
     gi = {int(a): i for i, a in enumerate(ga)}
-    out = dict(ref=len(ra), got=len(ga), common=0, class_flips=0, max_dbox=0.0, max_dscore=0.0)
+    n0, n1 = (H // 8) * (W // 8), (H // 16) * (W // 16)
+    out = dict(ref=len(ra), got=len(ga), common=0, class_flips=0, max_dbox=0.0, max_dbox_strides=0.0, max_dscore=0.0)
     for j, a in enumerate(ra):
         i = gi.get(int(a))
         if i is None:
             continue
         out["common"] += 1
         out["class_flips"] += int(int(gc[i]) != int(rc[j]))
-        out["max_dbox"] = max(out["max_dbox"], float(np.abs(gb[i] - rb[j]).max()))
+        d = float(np.abs(gb[i] - rb[j]).max())
+        stride = 8.0 if int(a) < n0 else (16.0 if int(a) < n0 + n1 else 32.0)
+        out["max_dbox"] = max(out["max_dbox"], d)
+        out["max_dbox_strides"] = max(out["max_dbox_strides"], d / stride)
         out["max_dscore"] = max(out["max_dscore"], float(abs(gs[i] - rs[j])))
     return out
 
 
 def sum_nms_reports(reports):
-    tot = dict(ref=0, got=0, common=0, class_flips=0, max_dbox=0.0, max_dscore=0.0)
+    tot = dict(ref=0, got=0, common=0, class_flips=0, max_dbox=0.0, max_dbox_strides=0.0, max_dscore=0.0)
     for r in reports:
         for k in ("ref", "got", "common", "class_flips"):
             tot[k] += r[k]
-        for k in ("max_dbox", "max_dscore"):
+        for k in ("max_dbox", "max_dbox_strides", "max_dscore"):
             tot[k] = max(tot[k], r[k])
     return tot

@@ -1,0 +1,107 @@
+"""The drop-in boundary driven the way the reference drives it:
+  * the model call with EXACTLY the keyword set of caesar_yolo/evaluation.py:181-193 (incl. device='cpu', the reference's
+    default `--devices=cpu`, scripts/run.py:130) and the result access of :261-265;
+  * `Analyzer(model, config).predict(image, image_id, header, xmin, ymin)` (:128-245): return codes, `.results`,
+    tile-origin offsets, the object name tag, rejection of None / constant-row images."""
+import json
+import os
+import numpy as np
+import pytest
+from gpu_common import seeded_weights, oracle_model, ROOT
+
+pytestmark = pytest.mark.gpu
+CONF, IOU, SOFT, HARD = 0.7, 0.5, 0.3, 0.8
+
+
+def _galaxy_cube():
+    from caesar_yolo_amd import utils
+    from oracle import preprocessing_ref as P
+    data, _ = utils.read_fits_image(os.path.join(ROOT, "tests/golden/galaxy0001.fits"))
+    img = np.asarray(data, np.float32)
+    dp = P.build_pipeline([("zscale", dict(contrasts=[0.25] * 3)), ("minmax", dict(norm_min=0, norm_max=255))])
+    return img, dp(P.to_cube(img))
+
+
+def test_model_call_with_the_reference_keyword_set(caplog):
+    from caesar_yolo_amd.model import YOLO
+    img, cube = _galaxy_cube()
+    model = YOLO(seeded_weights()[0], precision="fp32", max_batch=1, max_imgsz=640)
+    assert isinstance(model.names, dict) and len(model.names) == 5
+    # caesar_yolo/evaluation.py:181-193, verbatim keyword set; the image is the (H,W,3) float64 cube in [0,255]
+    results = model(cube, save=False, device="cpu", imgsz=640, conf=CONF, iou=IOU, visualize=False, show=False,
+                    show_labels=False, show_conf=False, show_boxes=False)
+    got = []
+    for result in results:                                       # :261-265
+        bboxes = result.boxes.xyxy.cpu().numpy()
+        scores = result.boxes.conf.cpu().numpy()
+        labels = result.boxes.cls.cpu().numpy()
+        got.append((bboxes, scores, labels))
+        for c in labels:
+            assert int(c) in model.names
+    assert len(got) == 1
+    det, _, _, _ = oracle_model().predict_raw(cube, 640, CONF, IOU)
+    b, s, c = got[0]
+    assert b.dtype == np.float32 and b.shape == (len(s), 4) and len(s) == det.shape[0] and len(s) > 0
+    np.testing.assert_allclose(s, det[:, 4].numpy(), atol=1e-4)
+    np.testing.assert_array_equal(c.astype(int), det[:, 5].numpy().astype(int))
+    np.testing.assert_allclose(b, det[:, :4].numpy(), atol=132 * 1e-4)
+    assert (np.diff(s) <= 0).all() and b.min() >= 0 and b.max() <= 132          # conf-descending, clipped to the image
+
+
+def test_analyzer_predict_contract(tmp_path, monkeypatch):
+    from caesar_yolo_amd.model import YOLO
+    from caesar_yolo_amd.evaluation import Analyzer
+    from caesar_yolo_amd.config import CONFIG
+    from caesar_yolo_amd import preprocessing as PP
+    from oracle import postproc_ref as R
+    monkeypatch.chdir(tmp_path)
+    img, cube = _galaxy_cube()
+    model = YOLO(seeded_weights()[0], precision="fp32", max_batch=1, max_imgsz=640)
+    c = dict(CONFIG)
+    c.update(img_size=640, preprocess_fcn=PP.DataPreprocessor([PP.ZScaleTransformer([0.25] * 3), PP.MinMaxNormalizer(0, 255)]),
+             score_thr=CONF, iou_thr=IOU, merge_overlap_iou_thr_soft=SOFT, merge_overlap_iou_thr_hard=HARD, devices=["cpu"])
+    an = Analyzer(model, c)
+    an.obj_name_tag = "t7"
+    assert an.predict(img, image_id="galaxy0001", header=None, xmin=1000, ymin=2000) == 0
+    det, _, _, _ = oracle_model().predict_raw(cube, 640, CONF, IOU)
+    kb, ks, kc, _ = R.process_detections(det[:, :4].numpy(), det[:, 4].numpy(), det[:, 5].numpy(), CONF, SOFT, HARD)
+    ref = R.make_objs(kb, ks, kc, model.names, 132, 132, 1000, 2000, "t7")
+    assert len(ref) > 0 and len(an.bboxes_final) == len(an.scores_final) == len(an.class_ids_final) == len(an.labels_final) == len(ref)
+    assert an.results["image_id"] == "galaxy0001" and len(an.results["objs"]) == len(ref)
+    for g, r in zip(an.results["objs"], ref):
+        assert set(g) == set(r) == {"name", "x1", "x2", "y1", "y2", "class_id", "class_name", "score", "edge"}
+        assert g["name"] == r["name"] and g["name"].endswith("_t7")
+        assert g["class_id"] == r["class_id"] and g["class_name"] == r["class_name"] and g["edge"] == r["edge"]
+        assert abs(g["score"] - r["score"]) <= 1e-4
+        for k in ("x1", "x2", "y1", "y2"):
+            assert abs(g[k] - r[k]) <= 1.0 and g[k] >= 1000 - 1                  # tile origin added (evaluation.py:460-463)
+    assert json.load(open(tmp_path / "out_galaxy0001.json")) == json.loads(json.dumps(an.results))
+    # rejections: a None image, a pipeline that returns None (all zero), constant first rows (Q1) -> -1, nothing written
+    assert an.predict(None) == -1
+    assert Analyzer(model, c).predict(np.zeros((132, 132), np.float32), image_id="z") == -1
+    q = img.copy()
+    q[1, :] = 0.0
+    assert Analyzer(model, c).predict(q, image_id="q") == -1
+    assert not os.path.exists(tmp_path / "out_z.json") and not os.path.exists(tmp_path / "out_q.json")
+
+
+def test_counters_report_candidate_overflow_and_degenerate_boxes():
+    """A context with a deliberately small candidate capacity counts the tiles that overflow it (cy_detect_counters); the
+    default capacity (= anchor count) cannot overflow even at conf 0."""
+    from caesar_yolo_amd.model import HipDetector
+    from caesar_yolo_amd import preprocessing as PP
+    g = np.load(os.path.join(ROOT, "tests/golden/preproc.npz"))
+    img = np.ascontiguousarray(g["in/syn192"])
+    cfg = PP.DataPreprocessor([PP.ZScaleTransformer([0.25] * 3), PP.MinMaxNormalizer(0, 255)]).program()
+    small = HipDetector(seeded_weights()[0], device=0, precision="fp16", max_batch=2, max_imgsz=192, max_cand=64)
+    mosaic = small.mosaic_to_device(img)
+    small.counters(reset=True)
+    small.detect_tiles(mosaic, [(0, 0), (0, 0)], 192, 192, 192, cfg, 0.001, IOU, SOFT, HARD)
+    assert small.counters(reset=True)["cand_overflow_tiles"] == 2
+    assert small.counters()["cand_overflow_tiles"] == 0
+    small.close()
+    full = HipDetector(seeded_weights()[0], device=0, precision="fp16", max_batch=2, max_imgsz=192)
+    mosaic = full.mosaic_to_device(img)
+    d, cnt, st = full.detect_tiles(mosaic, [(0, 0)], 192, 192, 192, cfg, 0.0, IOU, SOFT, HARD)
+    assert full.counters()["cand_overflow_tiles"] == 0 and int(cnt[0]) > 0
+    full.close()

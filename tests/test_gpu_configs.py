@@ -19,14 +19,16 @@ import config_common as CC
 
 pytestmark = pytest.mark.gpu
 
-# Stated bounds of the fp16 context (fp16 operands, fp32 accumulate; what bench.py measures) against the fp32 oracle.  The conf
-# cut (score > 0.7), NMS (IoU > 0.5) and the IoU merge's "best score of a component" are discontinuities: a 3e-3 score
-# wiggle moves a candidate across the cut or changes which member of a merged group survives (then the BOX changes by tens of
-# pixels although every logit is within tolerance).  So the bounds are on set agreement, and box/score deltas are stated on
-# boxes that are the SAME anchor in both runs.  Measured values: DESIGN.md section 2.
+# Stated bounds of the fp16 context (fp16 operands, fp32 accumulate; what bench.py measures) against the fp32 oracle, on the
+# seeded random-init weights every run here uses.  Three kinds of discontinuity amplify the ~1e-2 logit noise of fp16 operands:
+# the conf cut (score > 0.7) and NMS (IoU > 0.5) move single anchors in or out; the IoU merge keeps "the best score of a
+# component", so a 3e-3 score wiggle can change WHICH member survives (then the box changes by tens of pixels although every
+# logit is within tolerance); and with random weights the DFL bin distributions are broad, so a box edge (= the expectation
+# over 16 bins x stride) moves by a fraction of a stride.  Hence: set agreement at every level, score deltas on identical
+# anchors, box deltas in units of the anchor's stride.  Measured values: DESIGN.md section 2.
 FP16_NMS_MIN_COMMON = 0.95       # kept-anchor sets after NMS: |common| / |oracle kept|
 FP16_NMS_MAX_EXTRA = 0.05        # (|fp16 kept| - |common|) / |oracle kept|
-FP16_NMS_MAX_DBOX = 1.0          # px, same anchor in both runs
+FP16_NMS_MAX_DBOX_STRIDES = 0.5  # same anchor in both runs: box delta / stride of the anchor's level (8, 16 or 32 px)
 FP16_MAX_DSCORE = 2e-2           # same anchor / matched source
 FP16_MIN_MATCHED = 0.95          # after the IoU merge and in the final catalog: same class, IoU >= 0.5
 FP16_MAX_EXTRA = 0.05
@@ -118,7 +120,7 @@ def test_config_fp16_delta_vs_oracle(name, tmp_path):
             if status[b] != 0:
                 continue
             n = int(cnt[b])
-            nms_reports.append(CC.nms_level_report((d[b, :n, :4], d[b, :n, 4], d[b, :n, 5], anch[b, :n]), ref["raw"][t]))
+            nms_reports.append(CC.nms_level_report((d[b, :n, :4], d[b, :n, 4], d[b, :n, 5], anch[b, :n]), ref["raw"][t], lb.H, lb.W))
             k = int(mcnt[b])
             reports.append(CC.match_sets((m[b, :k, :4], m[b, :k, 4], m[b, :k, 5]), ref["dets"][t]))
             nref += len(ref["dets"][t][1])
@@ -131,7 +133,7 @@ def test_config_fp16_delta_vs_oracle(name, tmp_path):
                                        "candidates_within_1e-3_of_conf": ref["near"]}))
     assert nms_rep["ref"] > 0 and nms_rep["common"] >= FP16_NMS_MIN_COMMON * nms_rep["ref"], nms_rep
     assert nms_rep["got"] - nms_rep["common"] <= max(2, FP16_NMS_MAX_EXTRA * nms_rep["ref"]), nms_rep
-    assert nms_rep["max_dbox"] <= FP16_NMS_MAX_DBOX and nms_rep["max_dscore"] <= FP16_MAX_DSCORE, nms_rep
+    assert nms_rep["max_dbox_strides"] <= FP16_NMS_MAX_DBOX_STRIDES and nms_rep["max_dscore"] <= FP16_MAX_DSCORE, nms_rep
     for rep, n in ((tile_rep, nref), (cat_rep, len(ref["catalog"]))):
         assert n > 0
         assert rep["matched"] >= FP16_MIN_MATCHED * n, rep
