@@ -11,8 +11,9 @@ line and exits with the children's status.  Launched under torch.distributed.run
 Workload "s16k" = BASELINE.json configs[2]/[3]: a seeded synthetic 16384x16384 single-channel mosaic (caesar_yolo_amd/synth.py),
 512x512 tiles at step 0.8 -> 1600 tiles (1521 full, 39+39 ragged, 1 corner), --preprocessing zscale(0.25) + minmax(0,255),
 imgsz 512, conf 0.7, NMS IoU 0.5, merge thresholds 0.3/0.8, yolov8l nc=5 with seeded random-init weights.
-Workload "c5" = BASELINE.json configs[4] at one-GPU size: the S32k recipe at 8192x8192, --chan3_preproc 3-channel preprocessing,
-640x640 tiles at step 0.8 -> 256 tiles, imgsz 640 (reported under its own metric name; the default and the headline is s16k).
+Workload "c5" = BASELINE.json configs[4] at one-GPU size: the S32k recipe at 16384x16384, --chan3_preproc 3-channel preprocessing,
+640x640 tiles at step 0.8 -> 1024 tiles (961 full + 63 ragged; the 32k mosaic has 3969 + 127), imgsz 640 (reported under its own
+metric name; the default and the headline is s16k).
 
 One STEP = one full pass over the mosaic's tile grid: every tile of this rank's share through crop -> preprocessing ->
 letterbox/pack -> YOLOv8l forward -> decode/NMS -> IoU merge (all on device, fp16 operands / fp32 accumulate), then ONE
@@ -35,8 +36,8 @@ WORKLOADS = {
     # name: mosaic edge, seed, tile, step, imgsz, algorithmic conv FLOPs per full tile (yolov8l nc=5)
     "s16k": dict(size=16384, seed=20260104, tile=512, step=0.8, imgsz=512, flop=105.488e9, batch=256,
                  metric="512x512 tiles/sec over 16k x 16k FITS", pre="zscale+minmax"),
-    "c5": dict(size=8192, seed=20260105, tile=640, step=0.8, imgsz=640, flop=164.825e9, batch=128,
-               metric="640x640 chan3 tiles/sec over 8k x 8k FITS (config 5 at one-GPU size)", pre="chan3+minmax"),
+    "c5": dict(size=16384, seed=20260105, tile=640, step=0.8, imgsz=640, flop=164.825e9, batch=128,
+               metric="640x640 chan3 tiles/sec over 16k x 16k FITS (config 5 at one-GPU size)", pre="chan3+minmax"),
 }
 
 

@@ -1298,6 +1298,11 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
         }
     };
 
+    // (tried in round 2, not kept: s_setprio 1 for waves 4-7 before the loop -- static priority for the second-dispatched half,
+    // MI355X_MICROARCH.md "Two waves per SIMD" item 4: 8026 vs 8048 tiles/s on the S16k benchmark; and a PERSISTENT form, one
+    // workgroup per CU walking the patches with the next patch's halo / first weight stages requested behind the last stage
+    // barrier so that their round trip runs under the epilogue: 7807 vs 7851 tiles/s with the same restructured body, which
+    // itself cost 2.5 % through spills at the 256-VGPR limit -- the exposed prologue is not where the time goes)
     // prologue: halo of slab 0, weight stages 0 and 1
     dma_patch(0, 0);
     dma_stage(0, 0, 0);

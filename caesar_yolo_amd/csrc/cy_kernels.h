@@ -78,6 +78,7 @@ enum ConvVariant { CONV_GENERIC_128 = 0, CONV_GENERIC_64, CONV_HALO8_128, CONV_P
 int conv_variant(Precision p, const ConvArgs& a);          // which kernel launch_conv picks
 const char* conv_variant_name(int v);
 void debug_read_stamps(unsigned long long* out8, bool reset);   // developer diagnostics (CY_DBG=64)
+void debug_read_pre_stamps(unsigned long long* out8, bool reset);   // phases of pre_stats_kernel (cy_preproc.hip), stamped builds only
 hipError_t launch_stem(Precision p, const StemArgs& a, hipStream_t s);
 hipError_t launch_stem_down(const StemDownArgs& a, hipStream_t s);
 long stem_down_blocks(const StemDownArgs& a);
@@ -150,6 +151,7 @@ struct PreArgs {
     void* out; int out_prec; int H, W, top, left;   // NHWC4 letterboxed canvas, fill 114/255
     double* scratch;                       // [B][3][th*tw] fp64 preprocessed image when a resize is needed, else null
     int new_h, new_w;                      // resized size (== th,tw when no resize)
+    int* counters;                         // context counters or null: [2] += median-bracket hits, [3] += misses (cy_preproc.hip)
 };
 hipError_t launch_preproc(const PreArgs& a, hipStream_t s);
 hipError_t launch_letterbox_pack(const PreArgs& a, hipStream_t s);   // uses scratch/th/tw/new_*/H/W/top/left/out only

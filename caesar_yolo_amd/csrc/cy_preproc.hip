@@ -30,11 +30,28 @@
 
 namespace cy {
 
+// developer diagnostics (-DCY_STAMPS_ENABLED=1 builds only): shader cycles spent in the phases of the statistics kernel, summed
+// over workgroups: [0] moments passes, [1] radix-select medians, [2] bracket selections in LDS, [3] everything else of a sigma-clip run,
+// [4] zscale, [5] histeq, [6] minmax
+#ifndef CY_STAMPS_ENABLED
+#define CY_STAMPS_ENABLED 0
+#endif
+__device__ unsigned long long g_pre_stamps[8];
+__device__ __forceinline__ unsigned long long pre_now() { return CY_STAMPS_ENABLED ? __builtin_amdgcn_s_memtime() : 0ull; }
+__device__ __forceinline__ void pre_acc(int slot, unsigned long long t0) {
+    if (CY_STAMPS_ENABLED && threadIdx.x == 0) atomicAdd(&g_pre_stamps[slot], __builtin_amdgcn_s_memtime() - t0);
+}
+void debug_read_pre_stamps(unsigned long long* out8, bool reset) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_pre_stamps), 8 * sizeof(unsigned long long));
+    if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_pre_stamps), z, sizeof(z)); }
+}
+
 constexpr int NT = 1024;            // threads per statistics workgroup
 constexpr int NWAVE = NT / 64;
 constexpr int PSTRIDE = MAX_STAGES * 4;
 constexpr int HEQ_STRIDE = 520;     // 256 centres + 256 cdf (+pad) doubles per (tile, channel)
-constexpr int PXU = 4;              // pixels per thread in flight in a pass
+constexpr int NCAND = 24576;        // capacity of the median bracket (raw keys in LDS, 96 KiB)
 
 __device__ __forceinline__ bool cond_of(double v) { return v != 0.0 && isfinite(v); }
 
@@ -85,6 +102,8 @@ struct Smem {
     double q0[MAX_STAGES], q1[MAX_STAGES];
     double par[MAX_STAGES * 4];          // ... and the parameters solved so far
     unsigned long long bcu[4];
+    unsigned ncand;                      // raw keys of the set members inside the median bracket of the current pass
+    unsigned cand[NCAND];
 };
 
 __device__ __forceinline__ double chain_value(const Smem& s, int upto, double raw) {
@@ -155,43 +174,65 @@ __device__ __forceinline__ float fkey_inv(unsigned k) {
 
 struct TileView {
     const float* base; int MW, tw, th, npix;
+    __amdgpu_buffer_rsrc_t rs;            // the tile's rows as a raw buffer (range-checked 16-byte loads)
     __device__ __forceinline__ double raw(int i) const { const int y = i / tw, x = i - y * tw; return (double)base[(size_t)y * MW + x]; }
 };
 
-// membership of a pixel in the current sigma-clip set
-struct ClipSet { double L, U; int use_box, bx0, bx1, by0, by1; };
+// membership of a pixel in the current sigma-clip set.  Lf / Uf: the same bounds for a stage that reads the RAW pixels (no
+// earlier stage in its channel program): (double)r >= L  <=>  r >= Lf with Lf the smallest float not below L, so the test
+// runs in fp32 without a conversion (the passes are instruction-bound: ~70 instructions per pixel in the generic form)
+struct ClipSet { double L, U; int use_box, bx0, bx1, by0, by1; float Lf, Uf; };
+__device__ __forceinline__ float f_not_below(double x) { float f = (float)x; if ((double)f < x) f = nextafterf(f, INFINITY); return f; }
+__device__ __forceinline__ float f_not_above(double x) { float f = (float)x; if ((double)f > x) f = nextafterf(f, -INFINITY); return f; }
+__device__ __forceinline__ void set_bounds(ClipSet& cs, double L, double U) { cs.L = L; cs.U = U; cs.Lf = f_not_below(L); cs.Uf = f_not_above(U); }
 
-// One pass over the tile, PXU pixels per thread in flight (every statistics pass re-reads the raw tile, 1-1.6 MB per
-// workgroup; with one dependent load per thread the passes were latency-bound).  The replayed values of a batch are computed
-// before any of them is consumed, so the program / parameter reads from LDS are shared by the batch.
-// f(raw fp32, value, in_box, ok) is called by every lane of the workgroup (ok = false past the end): it may ballot.
-template <typename F>
+// One pass over the tile.  A thread owns groups of FOUR consecutive pixels of a row (one 16-byte buffer load, alignment 4)
+// and keeps PXG groups in flight: every statistics pass re-reads the raw tile (1-1.6 MB per workgroup, far more than an
+// XCD's L2 holds for its 32 workgroups), so a pass is bound by memory latency x bytes in flight; with one dword per thread
+// and load the 16 waves of a CU had 16 KB in flight (~8 GB/s per CU), now 128 KB.  The replayed values of a group are
+// computed before any of them is consumed, so the program / parameter reads from LDS are shared by the group.
+// f(raw fp32, value, in_box, ok) is called by every lane of the workgroup (ok = false past the row end / tile end): it may ballot.
+// RAW = true: the stage reads the raw pixels (upto == 0): value = (double)raw, nothing to replay.
+constexpr int PXG = 2;
+template <bool RAW, typename F>
 __device__ __forceinline__ void for_pixels(const Smem& s, const TileView& tv, int upto, const ClipSet* box, F&& f) {
-    // (y, x) of the thread's next pixel, advanced by NT pixels per load: one integer division per pass, not per pixel
-    int y = (int)threadIdx.x / tv.tw, x = (int)threadIdx.x - y * tv.tw;
-    const int dy = NT / tv.tw, dx = NT - dy * tv.tw;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int GR = (tv.tw + 3) >> 2, NG = tv.th * GR;            // groups per row, groups in the tile
+    // (y, gx) of the thread's next group, advanced by NT groups per load: one integer division per pass, not per group
+    int y = (int)threadIdx.x / GR, gx = (int)threadIdx.x - y * GR;
+    const int dy = NT / GR, dx = NT - dy * GR;
     const bool use_box = box && box->use_box;
-    for (int i0 = 0; i0 < tv.npix; i0 += PXU * NT) {
-        float r[PXU];
-        bool ok[PXU], inb[PXU];
+    for (int g0 = 0; g0 < NG; g0 += PXG * NT) {
+        f32x4 r[PXG];
+        int yy[PXG], xx[PXG];
 #pragma unroll
-        for (int u = 0; u < PXU; ++u) {
-            const int i = i0 + u * NT + (int)threadIdx.x;
-            ok[u] = i < tv.npix;
-            r[u] = ok[u] ? tv.base[(size_t)y * tv.MW + x] : 0.0f;
-            inb[u] = use_box && y >= box->by0 && y < box->by1 && x >= box->bx0 && x < box->bx1;
-            x += dx; y += dy;
-            if (x >= tv.tw) { x -= tv.tw; ++y; }
+        for (int u = 0; u < PXG; ++u) {
+            const int g = g0 + u * NT + (int)threadIdx.x;
+            yy[u] = g < NG ? y : -1; xx[u] = gx << 2;
+            const unsigned off = g < NG ? (unsigned)(y * tv.MW + (gx << 2)) * 4u : 0xFFFFFF00u;   // past the end: range check -> zeros
+            r[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(tv.rs, off, 0, 0));
+            gx += dx; y += dy;
+            if (gx >= GR) { gx -= GR; ++y; }
         }
-        double v[PXU];
 #pragma unroll
-        for (int u = 0; u < PXU; ++u) v[u] = chain_value(s, upto, (double)r[u]);
+        for (int u = 0; u < PXG; ++u) {
+            double v[4];
 #pragma unroll
-        for (int u = 0; u < PXU; ++u) f(r[u], v[u], inb[u], ok[u]);
+            for (int e = 0; e < 4; ++e) v[e] = RAW ? (double)r[u][e] : chain_value(s, upto, (double)r[u][e]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int x = xx[u] + e;
+                const bool ok = yy[u] >= 0 && x < tv.tw;
+                const bool inb = use_box && yy[u] >= box->by0 && yy[u] < box->by1 && x >= box->bx0 && x < box->bx1;
+                f(r[u][e], v[e], inb, ok);
+            }
+        }
     }
 }
 
-__device__ __forceinline__ bool in_set(const ClipSet& cs, double v, bool in_box) {
+template <bool RAW>
+__device__ __forceinline__ bool in_set(const ClipSet& cs, float r, double v, bool in_box) {
+    if (RAW) return r != 0.0f && !in_box && r >= cs.Lf && r <= cs.Uf;     // (the resident mosaic holds no non-finite values)
     return cond_of(v) && !in_box && v >= cs.L && v <= cs.U;
 }
 
@@ -250,6 +291,7 @@ __device__ __forceinline__ void clear_hists(Smem& s, bool both) {
 }
 
 // Median of the set (n >= 1 members) given the level-0 histogram of its raw keys in s.histA (top 11 bits): two more passes.
+template <bool RAW>
 __device__ __forceinline__ double set_median(Smem& s, const TileView& tv, int upto, const ClipSet& cs, unsigned long long n) {
     unsigned long long kA = (n - 1) / 2, kB = n / 2;                 // equal for odd n
     unsigned pA = 0u, pB = 0u, pmask = 0u;
@@ -262,8 +304,8 @@ __device__ __forceinline__ double set_median(Smem& s, const TileView& tv, int up
             __syncthreads();
             clear_hists(s, two);
             __syncthreads();
-            for_pixels(s, tv, upto, &cs, [&](float rf, double v, bool inb, bool act) {
-                act = act && in_set(cs, v, inb);
+            for_pixels<RAW>(s, tv, upto, &cs, [&](float rf, double v, bool inb, bool act) {
+                act = act && in_set<RAW>(cs, rf, v, inb);
                 const unsigned key = fkey(rf);
                 const unsigned bin = (key >> shift) & nbm;
                 hist_add(s.histA, bin, act && (key & pmask) == pA);
@@ -283,23 +325,105 @@ __device__ __forceinline__ double set_median(Smem& s, const TileView& tv, int up
     return 0.5 * (a + b);
 }
 
-struct ClipStats { double lo, hi, mean, median, std; unsigned long long n; };
+struct ClipStats { double lo, hi, mean, median, std; unsigned long long n; int hits, misses; };   // hits / misses of the median bracket
 
-// count and the moments about K of the current set, plus the level-0 radix histogram of its raw keys (s.histA)
-__device__ __forceinline__ void set_moments(Smem& s, const TileView& tv, int upto, const ClipSet& cs, double K,
-                                            unsigned long long* n_out, double* mean_out, double* std_out) {
+// One pass over the set: count and moments about K; optionally the level-0 radix histogram of the raw keys (s.histA); and,
+// given a bracket [vl, vh] of values around the expected median, the number of members below it and the raw keys of the
+// members inside it (s.cand, up to NCAND), from which the median is then selected without another pass over the tile.
+struct Bracket { double vl, vh; bool on; float lf, hf; bool collect; };   // collect = false: only count the members inside
+// The loop of a moments pass, specialised at compile time (the passes are instruction-bound: every per-pixel branch and every
+// replayed stage costs).  MODE 0: count and moments only; 1: + level-0 radix histogram (s.histA); 2: + count of the members
+// inside the bracket and below it; 3: + collect the raw keys of the members inside the bracket (s.cand / s.ncand).
+// Moments are accumulated branch-free (a pixel outside the set adds 0); a thread appends the candidates of a 4-pixel group
+// with ONE LDS atomic, and only when it has any (~15 % of the groups at the default bracket width).
+template <bool RAW, int MODE>
+__device__ __forceinline__ void moments_loop(Smem& s, const TileView& tv, int upto, const ClipSet& cs, double K, const Bracket& br,
+                                             double& s1, double& s2, unsigned& ucnt, unsigned& below, unsigned& ucand) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int GR = (tv.tw + 3) >> 2, NG = tv.th * GR;
+    int y = (int)threadIdx.x / GR, gx = (int)threadIdx.x - y * GR;
+    const int dy = NT / GR, dx = NT - dy * GR;
+    const bool partial = (tv.tw & 3) != 0;                    // the last group of a row reaches past the tile
+    for (int g0 = 0; g0 < NG; g0 += PXG * NT) {
+        f32x4 r[PXG];
+        int yy[PXG], xx[PXG];
+#pragma unroll
+        for (int u = 0; u < PXG; ++u) {
+            const int g = g0 + u * NT + (int)threadIdx.x;
+            yy[u] = y; xx[u] = gx << 2;
+            const unsigned off = g < NG ? (unsigned)(y * tv.MW + (gx << 2)) * 4u : 0xFFFFFF00u;   // past the end: zeros = not in any set
+            r[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(tv.rs, off, 0, 0));
+            gx += dx; y += dy;
+            if (gx >= GR) { gx -= GR; ++y; }
+        }
+#pragma unroll
+        for (int u = 0; u < PXG; ++u) {
+            double v[4];
+            bool act[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float rf = r[u][e];
+                v[e] = RAW ? (double)rf : chain_value(s, upto, (double)rf);
+                bool a = RAW ? (rf != 0.0f && rf >= cs.Lf && rf <= cs.Uf) : (cond_of(v[e]) && v[e] >= cs.L && v[e] <= cs.U);
+                if (partial) a = a && (xx[u] + e < tv.tw);
+                if (cs.use_box) a = a && !(yy[u] >= cs.by0 && yy[u] < cs.by1 && xx[u] + e >= cs.bx0 && xx[u] + e < cs.bx1);
+                act[e] = a;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const double d = v[e] - K, dm = act[e] ? d : 0.0;
+                s1 += dm; s2 += dm * dm; ucnt += act[e] ? 1u : 0u;
+            }
+            if (MODE == 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hist_add(s.histA, fkey(r[u][e]) >> 21, act[e]);
+            }
+            if (MODE >= 2) {
+                bool inbr[4];
+                unsigned k = 0u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float rf = r[u][e];
+                    inbr[e] = act[e] && (RAW ? (rf >= br.lf && rf <= br.hf) : (v[e] >= br.vl && v[e] <= br.vh));
+                    below += (act[e] && (RAW ? rf < br.lf : v[e] < br.vl)) ? 1u : 0u;
+                    k += inbr[e] ? 1u : 0u;
+                }
+                if (MODE == 2) ucand += k;
+                else if (k) {
+                    unsigned pos = atomicAdd(&s.ncand, k);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (inbr[e]) { if (pos < (unsigned)NCAND) s.cand[pos] = fkey(r[u][e]); ++pos; }
+                }
+            }
+        }
+    }
+}
+
+// One pass over the set: count and moments about K; optionally the level-0 radix histogram of the raw keys (s.histA); and,
+// given a bracket [vl, vh] of values around the expected median, the number of members below it and the raw keys of the
+// members inside it (s.cand, up to NCAND), from which the median is then selected without another pass over the tile.
+template <bool RAW>
+__device__ __forceinline__ void set_moments(Smem& s, const TileView& tv, int upto, const ClipSet& cs, double K, bool want_hist,
+                                            const Bracket& br, unsigned long long* n_out, double* mean_out, double* std_out,
+                                            unsigned long long* below_out, unsigned* ncand_out) {
     __syncthreads();
-    clear_hists(s, false);
+    if (want_hist) clear_hists(s, false);
+    if (threadIdx.x == 0) s.ncand = 0u;
     __syncthreads();
-    double cnt = 0.0, s1 = 0.0, s2 = 0.0;
-    for_pixels(s, tv, upto, &cs, [&](float rf, double v, bool inb, bool act) {
-        act = act && in_set(cs, v, inb);
-        if (act) { const double d = v - K; cnt += 1.0; s1 += d; s2 += d * d; }
-        hist_add(s.histA, fkey(rf) >> 21, act);
-    });
+    double s1 = 0.0, s2 = 0.0;
+    unsigned below = 0u, ucnt = 0u, ucand = 0u;
+    if (want_hist) moments_loop<RAW, 1>(s, tv, upto, cs, K, br, s1, s2, ucnt, below, ucand);      // (never together with a bracket)
+    else if (!br.on) moments_loop<RAW, 0>(s, tv, upto, cs, K, br, s1, s2, ucnt, below, ucand);
+    else if (!br.collect) moments_loop<RAW, 2>(s, tv, upto, cs, K, br, s1, s2, ucnt, below, ucand);
+    else moments_loop<RAW, 3>(s, tv, upto, cs, K, br, s1, s2, ucnt, below, ucand);
+    __syncthreads();
+    double bl = (double)below, cnt = (double)ucnt;
     block_sum3(s, cnt, s1, s2);
+    double nc = (double)ucand;
+    if (br.on && !want_hist) { bl = block_sum(s, bl); if (!br.collect) nc = block_sum(s, nc); }
     const unsigned long long n = (unsigned long long)cnt;
-    *n_out = n;
+    *n_out = n; *below_out = (unsigned long long)bl; *ncand_out = (br.on && !want_hist) ? (br.collect ? s.ncand : (unsigned)nc) : 0u;
     if (n) {
         const double m1 = s1 / cnt;                       // mean - K
         double var = s2 / cnt - m1 * m1;
@@ -308,12 +432,45 @@ __device__ __forceinline__ void set_moments(Smem& s, const TileView& tv, int upt
     } else { *mean_out = NAN; *std_out = NAN; }
 }
 
+// ranks kA <= kB (0-based) among the nc raw keys in s.cand: three radix levels over LDS
+__device__ __forceinline__ void select_cand(Smem& s, unsigned nc, unsigned long long kA, unsigned long long kB, unsigned* keyA, unsigned* keyB) {
+    unsigned pA = 0u, pB = 0u, pmask = 0u;
+#pragma unroll 1
+    for (int lvl = 0; lvl < 3; ++lvl) {
+        const int shift = lvl == 0 ? 21 : (lvl == 1 ? 10 : 0), nbits = lvl == 2 ? 10 : 11;
+        const unsigned nbm = (1u << nbits) - 1u;
+        const bool two = pA != pB;
+        __syncthreads();
+        clear_hists(s, two);
+        __syncthreads();
+        for (unsigned i0 = 0; i0 < nc; i0 += NT) {               // whole waves stay in the loop: hist_add ballots
+            const unsigned i = i0 + threadIdx.x;
+            const bool act = i < nc;
+            const unsigned key = act ? s.cand[i] : 0u;
+            const unsigned bin = (key >> shift) & nbm;
+            hist_add(s.histA, bin, act && (key & pmask) == pA);
+            if (two) hist_add(s.histB, bin, act && (key & pmask) == pB);
+        }
+        __syncthreads();
+        unsigned binA, binB; unsigned long long befA, befB;
+        locate2(s, s.histA, two ? s.histB : s.histA, 1 << nbits, kA, kB, &binA, &befA, &binB, &befB);
+        pA |= binA << shift; pB |= binB << shift;
+        kA -= befA; kB -= befB;
+        pmask |= nbm << shift;
+    }
+    *keyA = pA; *keyB = pB;
+}
+
 // astropy SigmaClip._sigmaclip_noaxis (maxiters 5, median centre, std spread) + statistics of the survivors
-// (sigma_clipped_stats).  One loop, one moments pass and one median per trip: the set's count, its moments about K and the
-// first radix level come out of ONE pass; K is the previous median (for the initial set: a first trip about 0 finds the
-// median, a second one accumulates about it), so var = E[d^2] - E[d]^2 loses nothing against numpy's two-pass form.
+// (sigma_clipped_stats).  Passes over the tile: 1 + 2 for the initial set (moments + first radix level, two more levels for
+// its exact median), 1 to accumulate its moments about that median (var = E[d^2] - E[d]^2 then loses nothing against numpy's
+// two-pass form), and ONE per clipping iteration: the pass that counts the clipped set and accumulates its moments about the
+// previous median also collects the raw keys inside a narrow bracket around that median (clipping moves the median by a
+// tiny fraction of sigma), and the new median is selected among them in LDS.  A bracket that misses the median or overflows
+// falls back to the three-pass radix select; the bracket width follows the density measured by the previous pass.
+template <bool RAW>
 __device__ __forceinline__ ClipStats sigma_clip_run(Smem& s, const TileView& tv, int upto, double slo, double sup, int use_box, double mask_fract) {
-    ClipSet cs{-INFINITY, INFINITY, use_box, 0, 0, 0, 0};
+    ClipSet cs{-INFINITY, INFINITY, use_box, 0, 0, 0, 0, -INFINITY, INFINITY};
     if (use_box) {
         const int xc = tv.tw / 2, yc = tv.th / 2;
         const int dy = (int)(tv.th * mask_fract / 2.0), dx = (int)(tv.tw * mask_fract / 2.0);
@@ -321,22 +478,69 @@ __device__ __forceinline__ ClipStats sigma_clip_run(Smem& s, const TileView& tv,
         if (cs.bx0 < 0) cs.bx0 = 0;          // numpy slice clamps (negative starts cannot occur for fract <= 1)
         if (cs.by0 < 0) cs.by0 = 0;
     }
-    ClipStats r{NAN, NAN, NAN, NAN, NAN, 0ull};
-    unsigned long long n = 0, nprev = ~0ull;
+    ClipStats r{NAN, NAN, NAN, NAN, NAN, 0ull, 0, 0};
+    unsigned long long n = 0, nprev = ~0ull, below = 0;
+    unsigned ncand = 0;
     double mean = NAN, sd = NAN, med = NAN, K = 0.0;
+    double density = 0.0;                     // set members per unit of value around the median (0: not measured yet)
+    // Half-width of the bracket in RANKS: a clip moves the median by about half the difference of the counts removed above
+    // and below it -- up to ~1 % of n on radio tiles (sources above +k sigma against the noise tail below) -- and the bracket
+    // must still hold it.  Capacity NCAND = 24576 keys = 1.5 x the full width.
+    constexpr double HALF_RANKS = 8192.0;
+    Bracket br{0.0, 0.0, false, 0.0f, 0.0f, true};
     int c = -2;                               // -2: first trip (about 0), -1: initial set about its median, >= 0: clips done
 #pragma unroll 1
     for (;;) {
-        set_moments(s, tv, upto, cs, K, &n, &mean, &sd);
+        const bool radix_trip = c == -2 || !br.on || !br.collect;   // this trip's median (if needed) comes from the radix select
+        unsigned long long ts = pre_now();
+        set_moments<RAW>(s, tv, upto, cs, K, radix_trip && c != -1, br, &n, &mean, &sd, &below, &ncand);
+        pre_acc(0, ts);
         if (c >= 1 && n == nprev) break;      // the clip removed nothing: converged, (mean, sd, med) describe this very set
         if (n == 0) { mean = sd = med = NAN; break; }
-        if (c != -1) med = set_median(s, tv, upto, cs, n);
-        if (c == -2) { K = med; c = -1; continue; }
+        if (br.on && ncand > 0) density = (double)ncand / (br.vh - br.vl);          // measured (also when the bracket overflowed or missed)
+        if (c != -1) {
+            const unsigned long long kA = (n - 1) / 2, kB = n / 2;
+            const bool hit = br.on && br.collect && ncand <= (unsigned)NCAND && below <= kA && kB < below + ncand;
+            if (br.on && br.collect) { if (hit) ++r.hits; else ++r.misses; }
+            if (hit) {
+                unsigned keyA, keyB;
+                ts = pre_now();
+                select_cand(s, ncand, kA - below, kB - below, &keyA, &keyB);
+                pre_acc(2, ts);
+                const double a = chain_value(s, upto, (double)fkey_inv(keyA));
+                med = keyA == keyB ? a : 0.5 * (a + chain_value(s, upto, (double)fkey_inv(keyB)));
+            } else {
+                if (!radix_trip) {            // the bracket missed (or overflowed): level-0 histogram first, then the two radix passes
+                    Bracket off{0.0, 0.0, false, 0.0f, 0.0f, true};
+                    unsigned long long n2, b2; unsigned c2; double m2, s2;
+                    set_moments<RAW>(s, tv, upto, cs, K, true, off, &n2, &m2, &s2, &b2, &c2);
+                }
+                ts = pre_now();
+                med = set_median<RAW>(s, tv, upto, cs, n);
+                pre_acc(1, ts);
+            }
+        }
+        if (c == -2) {
+            // second trip over the initial set: accurate moments about its median, and the density of members around the median
+            // (count inside +-sd/32; sd of the first trip is good enough for that) to size the first bracket
+            K = med; c = -1;
+            const double d0 = sd / 32.0;
+            br.on = sd > 0.0 && isfinite(d0); br.collect = false;
+            br.vl = med - d0; br.vh = med + d0; br.lf = f_not_below(br.vl); br.hf = f_not_above(br.vh);
+            continue;
+        }
         if (c == -1) c = 0;
         if (c == 5) break;                    // maxiters: statistics of the final survivors, bounds of the fifth iteration
         r.lo = med - sd * slo; r.hi = med + sd * sup;
-        cs.L = fmax(cs.L, r.lo); cs.U = fmin(cs.U, r.hi);
+        set_bounds(cs, fmax(cs.L, r.lo), fmin(cs.U, r.hi));
         nprev = n; K = med; ++c;
+        // bracket for the next trip: +-delta around the current median, delta from the measured density, else from sigma
+        // (a normal core has 0.4 n / sigma members per unit at its centre)
+        const double rho = density > 0.0 ? density : 0.4 * (double)n / sd;
+        const double delta = HALF_RANKS / rho;
+        br.on = sd > 0.0 && isfinite(delta) && delta > 0.0; br.collect = true;
+        br.vl = med - delta; br.vh = med + delta;
+        br.lf = f_not_below(br.vl); br.hf = f_not_above(br.vh);
     }
     r.mean = mean; r.median = med; r.std = sd; r.n = n;
     return r;
@@ -417,7 +621,7 @@ __device__ __forceinline__ void zscale_run(Smem& s, const TileView& tv, int upto
 // skimage equalize_hist tables: np.histogram(image, 256) over [min,max] (zeros included), cdf, bin centres
 __device__ __forceinline__ void histeq_run(Smem& s, const TileView& tv, int upto, double* heq_global) {
     double mn = INFINITY, mx = -INFINITY;
-    for_pixels(s, tv, upto, nullptr, [&](float, double v, bool, bool ok) {
+    for_pixels<false>(s, tv, upto, nullptr, [&](float, double v, bool, bool ok) {
         if (ok) { mn = fmin(mn, v); mx = fmax(mx, v); }
     });
     mn = block_min(s, mn); mx = block_max(s, mx);
@@ -428,7 +632,7 @@ __device__ __forceinline__ void histeq_run(Smem& s, const TileView& tv, int upto
     __syncthreads();
     clear_hists(s, false);
     __syncthreads();
-    for_pixels(s, tv, upto, nullptr, [&](float, double v, bool, bool act) {
+    for_pixels<false>(s, tv, upto, nullptr, [&](float, double v, bool, bool act) {
         int idx = 0;
         if (act) {
             idx = (int)(((v - first) / (last - first)) * 256.0);
@@ -478,18 +682,27 @@ __global__ __launch_bounds__(NT) void pre_stats_kernel(const PreArgs a) {
     const int tx0 = kint(ka + offsetof(PreArgs, txy) + (size_t)(2 * b) * 4), ty0 = kint(ka + offsetof(PreArgs, txy) + (size_t)(2 * b + 1) * 4);
     double* params = a.params + ((size_t)b * 3 + p) * PSTRIDE;
     double* heq = a.histeq + ((size_t)b * 3 + p) * HEQ_STRIDE;
-    TileView tv{a.mosaic + (size_t)ty0 * a.MW + tx0, a.MW, a.tw, a.th, a.tw * a.th};
+    const float* tbase = a.mosaic + (size_t)ty0 * a.MW + tx0;
+    // bytes addressable from the tile origin: up to the end of the mosaic (a 16-byte load of the last group of a row may
+    // reach into the next row or, on the mosaic's last row, past the end: there the range check returns zeros)
+    const size_t tbytes = ((size_t)(a.MH - ty0) * a.MW - tx0) * 4;
+    TileView tv{tbase, a.MW, a.tw, a.th, a.tw * a.th,
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tbase), 0, (unsigned)(tbytes > 0xFFFFFF00ull ? 0xFFFFFF00ull : tbytes), 0x00020000)};
     __syncthreads();
-    int status = 0;
+    int status = 0, hits = 0, misses = 0;
     for (int k = 0; k < nst; ++k) {
         const int op = s.op[k];
         const double p0 = s.q0[k], p1 = s.q1[k];
         const int flag = s.flag[k];
         double o0 = 0, o1 = 0, o2 = 0, o3 = 0;
+        const unsigned long long top = pre_now();
         if (op == OP_BKG || op == OP_SHIFT || op == OP_CLIP) {
             // astropy: `sigma_lower or sigma` -- a 0 falls back to the default sigma = 3
             const double slo = op == OP_CLIP ? (p0 != 0.0 ? p0 : 3.0) : p0, sup = op == OP_CLIP ? (p1 != 0.0 ? p1 : 3.0) : p0;
-            const ClipStats r = sigma_clip_run(s, tv, k, slo, sup, op == OP_BKG ? flag : 0, op == OP_BKG ? p1 : 0.0);
+            const int ubox = op == OP_BKG ? flag : 0;
+            const double fract = op == OP_BKG ? p1 : 0.0;
+            const ClipStats r = k == 0 ? sigma_clip_run<true>(s, tv, k, slo, sup, ubox, fract) : sigma_clip_run<false>(s, tv, k, slo, sup, ubox, fract);
+            hits += r.hits; misses += r.misses;
             if (op == OP_BKG) { o0 = r.mean; if (r.n == 0) status = 1; }
             else if (op == OP_SHIFT) { o0 = r.mean + p0 * r.std; o1 = r.mean; o2 = r.std; if (r.n == 0) status = 1; }
             else { o0 = r.lo; o1 = r.hi; if (r.n == 0 && isnan(r.lo)) status = 1; }
@@ -499,12 +712,13 @@ __global__ __launch_bounds__(NT) void pre_stats_kernel(const PreArgs a) {
             histeq_run(s, tv, k, heq);
         } else if (op == OP_MINMAX) {
             double mn = INFINITY, mx = -INFINITY;
-            for_pixels(s, tv, k, nullptr, [&](float, double v, bool, bool ok) {
+            for_pixels<false>(s, tv, k, nullptr, [&](float, double v, bool, bool ok) {
                 if (ok && cond_of(v)) { mn = fmin(mn, v); mx = fmax(mx, v); }
             });
             o0 = block_min(s, mn); o1 = block_max(s, mx); o2 = p0; o3 = p1;
             if (!(o0 <= o1)) status = 1;           // no non-zero finite pixel: the stage returns None (preprocessing.py:101-103)
         }
+        pre_acc(op == OP_ZSCALE ? 4 : (op == OP_HISTEQ ? 5 : (op == OP_MINMAX ? 6 : 3)), top);
         __syncthreads();
         if (threadIdx.x == 0) {
             params[k * 4] = o0; params[k * 4 + 1] = o1; params[k * 4 + 2] = o2; params[k * 4 + 3] = o3;
@@ -513,6 +727,7 @@ __global__ __launch_bounds__(NT) void pre_stats_kernel(const PreArgs a) {
         __syncthreads();
     }
     if (threadIdx.x == 0 && status) atomicMax(a.status + b, status);
+    if (threadIdx.x == 0 && a.counters && (hits | misses)) { atomicAdd(a.counters + 2, hits); atomicAdd(a.counters + 3, misses); }
 }
 
 // ---------------------------------------------------------------------------------------- apply + letterbox + pack

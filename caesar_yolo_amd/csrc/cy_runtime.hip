@@ -143,6 +143,53 @@ int parse_plan_v2(cy_ctx* c, Reader& r, Plan* plan, uint32_t* nconv_out, std::ve
     return CY_OK;
 }
 
+// A CYW2 file carries its own execution plan; it is untrusted data.  Every channel slice an op names must lie inside its
+// tensor, or the kernels would address outside the workspace (the tensors' extents are the buffer-resource bounds).
+std::string validate_plan(const Plan& p) {
+    auto T = [&](int t) -> const Tensor& { return p.tensors[t]; };
+    auto inside = [&](int t, int coff, int n) { return coff >= 0 && n >= 1 && coff + n <= T(t).C; };
+    for (size_t i = 0; i < p.ops.size(); ++i) {
+        const Op& o = p.ops[i];
+        const std::string at = " in op " + std::to_string(i);
+        if (o.kind == OPK_POOL) {
+            if (o.out < 0 || !inside(o.in0, o.in0_coff, o.c0) || !inside(o.out, o.out_coff, o.c0) || T(o.in0).level != T(o.out).level)
+                return "pool slice outside its tensor" + at;
+            continue;
+        }
+        if (o.kind == OPK_ATTN) {
+            const long need = (long)o.p0 * (2L * o.p1 + o.p2);
+            if (o.out < 0 || o.p0 < 1 || o.p1 < 1 || o.p2 < 1 || need > 65536 || !inside(o.in0, o.in0_coff, (int)need) ||
+                !inside(o.out, o.out_coff, o.p0 * o.p2))
+                return "attention slice outside its tensor" + at;
+            continue;
+        }
+        const ConvDesc& d = p.convs[o.conv];
+        if (o.kind == OPK_DWCONV) {
+            // input channel of output channel ch: (ch / blk) * gstride + goff + ch % blk   (blk = 0: ch)
+            const int last = d.cout - 1;
+            const long cin_last = o.p0 > 0 ? (long)(last / o.p0) * o.p1 + o.p2 + last % o.p0 : last;
+            if (o.out < 0 || o.p0 < 0 || o.p1 < 0 || o.p2 < 0 || (o.p0 > 0 && o.p0 % 8) || o.in0_coff < 0 ||
+                o.in0_coff + cin_last + 1 > T(o.in0).C || !inside(o.out, o.out_coff, d.cout) ||
+                (o.res >= 0 && !inside(o.res, o.res_coff, d.cout)))
+                return "depth-wise slice outside its tensor" + at;
+            continue;
+        }
+        if (o.kind == OPK_STEM) {
+            if (o.out < 0 || !inside(o.out, o.out_coff, d.cout) || T(o.in0).C != 4 || d.cin != 3) return "malformed stem" + at;
+            continue;
+        }
+        if (!inside(o.in0, o.in0_coff, o.c0) || (o.in1 >= 0 ? !inside(o.in1, o.in1_coff, o.c1) : o.c1 != 0) || o.c0 + o.c1 != d.cin)
+            return "conv input slice does not match " + d.name + at;
+        if (o.in1 >= 0 && (d.k != 1 || o.c0 % 64)) return "two-segment input needs a 1x1 conv and a 64-aligned boundary" + at;
+        if (o.up0 && (d.k != 1 || T(o.in0).level < 1)) return "upsampled input needs a 1x1 conv" + at;
+        if (o.out >= 0 && !inside(o.out, o.out_coff, d.cout)) return "conv output slice outside its tensor" + at;
+        if (o.out < 0 && (o.pred_coff < 0 || o.pred_coff + d.cout > 64 + p.nc)) return "head slice outside the prediction row" + at;
+        if (o.res >= 0 && (!inside(o.res, o.res_coff, d.cout) || (o.out >= 0 && T(o.res).level != T(o.out).level)))
+            return "residual slice outside its tensor" + at;
+    }
+    return "";
+}
+
 int upload_weights(cy_ctx* c, const void* buf, size_t nbytes) {
     Reader r{(const unsigned char*)buf, nbytes};
     if (nbytes < 24 || (memcmp(buf, "CYW1", 4) != 0 && memcmp(buf, "CYW2", 4) != 0)) return fail(c, CY_ERR_IO, "not a CYW weight file");
@@ -235,6 +282,10 @@ int upload_weights(cy_ctx* c, const void* buf, size_t nbytes) {
             HIPCHK(c, hipMalloc(&dc.w32, dc.w32bytes));
             HIPCHK(c, hipMemcpy(dc.w32, packed.data(), dc.w32bytes, hipMemcpyHostToDevice));
         }
+    }
+    if (v2) {
+        const std::string bad = validate_plan(plan);
+        if (!bad.empty()) { free_all(c); return fail(c, CY_ERR_IO, "malformed CYW2 plan: " + bad); }
     }
     c->plan = plan; c->names = names;
     // ---- workspace for (max_batch, max_h, max_w)
@@ -724,7 +775,12 @@ int cy_conv_bn_silu(cy_ctx* c, const void* d_in, int B, int Hi, int Wi, int Cin,
     return CY_OK;
 }
 
-int cy_debug_stamps(unsigned long long* out8, int reset) { if (!out8) return CY_ERR_ARG; debug_read_stamps(out8, reset != 0); return CY_OK; }
+int cy_debug_stamps(unsigned long long* out8, int reset) {
+    if (!out8) return CY_ERR_ARG;
+    if (reset >= 2) debug_read_pre_stamps(out8, reset == 3);       // 2 / 3: the statistics kernel's phase stamps (read / read + reset)
+    else debug_read_stamps(out8, reset != 0);
+    return CY_OK;
+}
 
 int cy_debug_cand_counts(cy_ctx* c, int* h_out, int B) {
     if (!c || !c->loaded || !h_out || B < 1 || B > c->cfg.max_batch) return fail(c, CY_ERR_ARG, "bad arguments");
@@ -774,7 +830,7 @@ int cy_preproc(cy_ctx* c, const float* d_mosaic, int MH, int MW, const int* h_ti
             a.prog[i].st[j] = PreStage{st.op, st.p0, st.p1, st.p2, st.flag};
         }
     }
-    a.params = c->S().pre_params; a.histeq = c->S().pre_histeq; a.status = d_status;
+    a.params = c->S().pre_params; a.histeq = c->S().pre_histeq; a.status = d_status; a.counters = c->counters;
     a.out = d_netin; a.out_prec = c->prec; a.H = lb.H; a.W = lb.W; a.top = lb.top; a.left = lb.left;
     a.new_h = lb.new_h; a.new_w = lb.new_w;
     const bool resize = (lb.new_h != th) || (lb.new_w != tw);

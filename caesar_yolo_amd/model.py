@@ -181,7 +181,8 @@ class HipDetector(object):
         """-> dict(degenerate_boxes, cand_overflow_tiles) accumulated since the last reset (synchronises the device)."""
         out = (C.c_longlong * 4)()
         self._chk(self.lib.cy_detect_counters(self.ctx, out, int(bool(reset))))
-        return {"degenerate_boxes": int(out[0]), "cand_overflow_tiles": int(out[1])}
+        return {"degenerate_boxes": int(out[0]), "cand_overflow_tiles": int(out[1]), "median_bracket_hits": int(out[2]),
+                "median_bracket_misses": int(out[3])}
 
     def detect_tiles(self, mosaic, tiles_xy, th, tw, imgsz, cfg, conf, iou, soft, hard, out=None, flush=True):
         """Whole per-tile path for B same-shape tiles.  Returns (det [B,300,6], count [B], status [B]) on device.

@@ -86,8 +86,15 @@ def _placeholder_class(module, name):
 
 def _rebuild_tensor(storage, offset, size, stride, *unused):
     arr, dtype_name = storage
+    offset = int(offset)
     size, stride = tuple(int(s) for s in size), tuple(int(s) for s in stride)
+    # a checkpoint is untrusted data: every element the view can reach must lie inside the storage blob (as_strided checks
+    # nothing: a negative offset or stride, or an oversized extent, would read process memory into the "weights")
+    if offset < 0 or len(size) != len(stride) or any(n < 0 for n in size) or any(st < 0 for st in stride):
+        raise PtImportError("malformed tensor view (negative offset, size or stride)")
     if len(size) == 0:
+        if offset + 1 > arr.size:
+            raise PtImportError("tensor view exceeds its storage")
         out = arr[offset:offset + 1].reshape(())
     else:
         need = offset + sum((n - 1) * st for n, st in zip(size, stride)) + 1 if all(n > 0 for n in size) else 0

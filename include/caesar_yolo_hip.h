@@ -136,7 +136,9 @@ int cy_detect_flush(cy_ctx* ctx, void* stream);
  * out4[0] degenerate boxes (x1 >= x2 or y1 >= y2) dropped before the IoU merge -- the reference aborts on them inside
  * get_iou's assert (caesar_yolo/utils.py:78-81); out4[1] tiles with more candidates than the
  * context's capacity (ultralytics keeps the top max_nms = 30000 by score; here the surplus is dropped in arrival order, so
- * a non-zero count means "raise max_cand"); out4[2..3] reserved.  Synchronises the device.  reset != 0 clears them. */
+ * a non-zero count means "raise max_cand"); out4[2], out4[3]: performance diagnostics of the sigma-clip statistics (median
+ * selections served by the one-pass bracket / fallen back to the three-pass radix select).  Synchronises the device.
+ * reset != 0 clears them. */
 int cy_detect_counters(cy_ctx* ctx, long long* out4, int reset);
 
 /* single fused Conv+bias+SiLU layer on caller tensors (kernel-level parity tests).

@@ -7,8 +7,10 @@ absent from /root/reference and from the container, as are cv2/torchvision and a
 Nothing in the reference's tests pins letterbox, forward or NMS outputs.  This file restates the public
 ultralytics-8.x detect pipeline as written down in SURVEY.md Appendix A.1 (LetterBox, /255, the
 yolov8.yaml graph with Conv+BN folded, Detect/DFL decode, non_max_suppression with torchvision-style
-nms, scale_boxes).  Self-consistency pins: parameter/FLOP counts reproduce the published yolov8l
-figures (tests/test_oracle_net.py).
+nms, scale_boxes).  Self-consistency pins (tests/test_oracle_net.py): the graph rebuilt independently as
+un-fused torch.nn modules (Conv2d + BatchNorm2d(eps=1e-3) + SiLU, C2f, SPPF, Detect) gives the same output on
+the folded weights; parameter/FLOP counts of THIS graph reproduce the published yolov8l figures; letterbox
+geometry on the shapes SURVEY.md Appendix A.1 lists.
 
 Everything is fp32 like the reference `--devices=cpu` run; the input image is float64 HWC in [0,255]
 exactly as Analyzer hands it over.

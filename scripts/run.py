@@ -4,10 +4,12 @@ accepted and ignored), same stage order for --preprocessing (:272-302), same CON
 
 Differences that come with the MI355X engine:
   --weights  takes a CYW1 file (caesar_yolo_amd/weights.py) or "seeded:<scale>:<nc>[:seed]";
-  --devices  lists GPU indices ("0", "cuda:0", "0,1,2,3"); "cpu" selects GPU LOCAL_RANK (there is no CPU path);
+  --devices  lists GPU indices ("0", "cuda:0", "0,1,2,3"); "cpu" (the reference's default) selects GPU LOCAL_RANK with a
+             warning: there is no CPU path;
+  --max_ntasks_per_worker  has no default here (the reference's 100 would refuse BASELINE configs 3-5); given, it is honoured;
   multi-GPU  = one process per GPU: `python -m torch.distributed.run --nproc-per-node N scripts/run.py ...`
              (replaces `mpirun -np N`, test/run_inference_parallel.sh:47-52);
-  --precision fp16|fp32, --tile_batch N  are new.
+  --precision fp32|fp16 (default fp32 = parity mode; fp16 = throughput mode), --tile_batch N  are new.
 """
 import argparse
 import logging
@@ -72,7 +74,9 @@ def parse_args(argv=None):
         p.add_argument('--' + a, dest=a, action='store_true')
     p.add_argument('--detect_outfile', type=str, default="")
     p.add_argument('--detect_outfile_json', type=str, default="")
-    p.add_argument('--precision', type=str, default="fp16", choices=["fp16", "fp32"])
+    p.add_argument('--precision', type=str, default="fp32", choices=["fp16", "fp32"],
+                   help='fp32 (default): exact-fp32 kernels, detections match the reference CPU run to 1e-4; fp16: fp16 operands / '
+                        'fp32 accumulate, ~16x the throughput, 2-3 %% of the detections differ (DESIGN.md section 2)')
     p.add_argument('--tile_batch', type=int, default=64)
     return p.parse_args(argv)
 

@@ -43,3 +43,37 @@ def test_cli_serial_and_tiled(tmp_path):
     # argument validation mirrors the reference: a missing image is an error exit, not a crash
     rc, _ = _run(["--image=" + str(tmp_path / "nope.fits"), "--weights=seeded:l:5"], str(tmp_path))
     assert rc == 1
+
+
+def test_cli_reference_defaults_and_tile_outputs(tmp_path):
+    """The reference's own defaults and optional outputs: --devices=cpu (scripts/run.py:130; here: GPU with a warning),
+    --save_tile_catalog / --save_tile_region / --save_tile_img (inference.py:220-229, :330-350), --bkg_chid, and the
+    max_ntasks_per_worker guard (inference.py:1151-1160) when it is given explicitly."""
+    from caesar_yolo_amd import utils
+    img = np.load(os.path.join(ROOT, "tests/golden/mosaic_b.npz"))["img"]
+    utils.write_fits_image(str(tmp_path / "mosaic_b.fits"), img)
+    base = ["--image=" + str(tmp_path / "mosaic_b.fits"), "--weights=seeded:l:5", "--preprocessing", "--subtract_bkg", "--bkg_chid=1",
+            "--zscale_stretch", "--normalize_minmax", "--norm_max=255", "--imgsize=256", "--split_img_in_tiles", "--tile_xsize=256",
+            "--tile_ysize=256", "--tile_xstep=1", "--tile_ystep=1", "--tile_batch=16", "--scoreThr=0.3", "--precision=fp16"]
+    rc, out = _run(base + ["--save_tile_catalog", "--save_tile_region", "--save_tile_img"], str(tmp_path))     # no --devices: the default "cpu"
+    assert rc == 0, out[-2000:]
+    assert "no CPU path" in out
+    src = json.load(open(tmp_path / "catalog_mosaic_b.json"))["sources"]
+    assert len(src) > 0
+    tiles = sorted(f for f in os.listdir(tmp_path) if f.startswith("catalog_mosaic_b_tid") and f.endswith(".json"))
+    assert 1 <= len(tiles) <= 16
+    n_objs = 0
+    for f in tiles:
+        t = json.load(open(tmp_path / f))
+        tid = int(f[len("catalog_mosaic_b_tid"):-5])
+        assert t["image_id"] == "mosaic_b"
+        for o in t["objs"]:
+            assert o["name"].endswith("_t%d" % tid)
+        n_objs += len(t["objs"])
+        assert os.path.exists(tmp_path / ("timg_mosaic_b_tid%d.fits" % tid))
+        assert os.path.exists(tmp_path / ("catalog_mosaic_b_tid%d.reg" % tid)) == (len(t["objs"]) > 0)
+    assert n_objs >= len(src)                                   # the cross-tile merge can only reduce the count
+    tile0, _ = utils.read_fits_image(str(tmp_path / ("timg_mosaic_b_tid%d.fits" % int(tiles[0][len("catalog_mosaic_b_tid"):-5]))))
+    assert tile0.shape == (256, 256)
+    rc, out = _run(base + ["--devices=0", "--max_ntasks_per_worker=4"], str(tmp_path))                           # 16 tiles on one rank > 4
+    assert rc == 1 and "Too many tasks per worker" in out

@@ -115,3 +115,21 @@ def test_yolo11_tile_path(tmp_path):
             np.testing.assert_array_equal(r.boxes.cls.cpu().numpy().astype(int), np.asarray(kc).astype(int))
             np.testing.assert_allclose(r.boxes.xyxy.cpu().numpy(), kb, atol=256 * 1e-4)
     assert total >= 4
+
+
+@pytest.mark.parametrize("field,delta", [("out_coff", 8), ("in0_coff", 8), ("res_coff", 1 << 20), ("c0", 64)])
+def test_malformed_cyw2_plan_is_refused(tmp_path, field, delta):
+    """The execution plan travels inside the weight file (CYW2): an op whose channel slice leaves its tensor must be refused
+    at load time, not make a kernel address outside the workspace."""
+    import copy
+    from caesar_yolo_amd import weights as W
+    from caesar_yolo_amd import lib as L
+    from caesar_yolo_amd.model import HipDetector
+    g, wd = seeded_folded("n", 3)
+    g = copy.deepcopy(g)
+    k = [i for i, o in enumerate(g.ops) if o["kind"] == 1 and o["out"] >= 0 and (field != "res_coff" or o["res"] >= 0)][3]
+    g.ops[k][field] += delta
+    path = str(tmp_path / "bad.cyw")
+    W.write_cyw2(path, g, [(cs, wd[cs.name][0], wd[cs.name][1]) for cs in g.convs], {0: "a", 1: "b", 2: "c"})
+    with pytest.raises(L.CyError, match="malformed CYW2 plan"):
+        HipDetector(path, device=0, precision="fp16", max_batch=1, max_imgsz=64)

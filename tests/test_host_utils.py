@@ -134,3 +134,62 @@ def test_generate_tiles_matches_reference_golden(golden_dir):
             assert got is None, name
         else:
             assert got is not None and [list(t) for t in got] == [list(t) for t in want], name
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_mosaic_source_uploads_only_the_ranks_regions(world):
+    """each rank holds only the rows its tiles touch.  With a MosaicSource the engine uploads the bounding box of
+    each shape-class segment of ITS tiles; at world 8 that is about 1/8 of the S16k mosaic (+ the overlap band), tile origins
+    are rebased to the region, and together the ranks still cover every tile."""
+    import torch
+    from caesar_yolo_amd.inference import TileEngine, MosaicSource
+
+    class FakeDet(object):
+        max_batch = 256
+        tdev = torch.device("cpu")
+
+        def __init__(self):
+            self.calls = []
+
+        def mosaic_to_device(self, arr, big_endian=None):
+            return torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32))
+
+        def detect_tiles(self, img, xy, th, tw, imgsz, cfg, conf, iou, soft, hard, out=None, flush=True):
+            for x, y in xy:
+                assert 0 <= x and x + tw <= img.shape[1] and 0 <= y and y + th <= img.shape[0]
+                self.calls.append((float(img[y, x]), th, tw))          # the pixel at the tile origin identifies the tile
+            return out
+
+    n = 4096
+    host = (np.arange(n, dtype=np.float32)[:, None] * n + np.arange(n, dtype=np.float32)[None, :])   # value = y * n + x (exact in fp32)
+    grid = utils.generate_tiles(0, n - 1, 0, n - 1, 512, 512, 0.8, 0.8)
+    seen, total = [], 0
+    for rank in range(world):
+        det, src = FakeDet(), MosaicSource(host)
+        eng = TileEngine(det, src, grid, None, 512, 0.7, 0.5, 0.3, 0.8, rank, world, batch=256)
+        eng.run_local()
+        for (_, tids) in eng.my:
+            for t in tids:
+                seen.append(t)
+        want = sorted((float(grid[t][2] * n + grid[t][0]), grid[t][3] - grid[t][2], grid[t][1] - grid[t][0]) for _, tids in eng.my for t in tids)
+        assert sorted(det.calls) == want                                # every tile was cropped at its own origin
+        total += src.bytes_uploaded
+        if world == 8:
+            assert src.bytes_uploaded <= 0.32 * host.nbytes            # on this small mosaic a two-row band is already 30 %
+    assert sorted(seen) == list(range(len(grid)))
+    if world == 1:
+        assert total <= 1.25 * host.nbytes                              # full tiles + the two ragged strips + the corner
+
+
+def test_rank_regions_of_the_16k_mosaic_are_an_eighth_plus_halo():
+    """The same rule on the benchmark grid, as arithmetic on the partition (no 1 GiB array): at 8 ranks every rank's regions
+    are at most 18 % of the 16384^2 mosaic (1/8 = 12.5 % + the 102-px overlap bands; the last rank also holds the ragged strips)."""
+    from caesar_yolo_amd.inference import partition_tiles
+    n = 16384
+    grid = utils.generate_tiles(0, n - 1, 0, n - 1, 512, 512, 0.8, 0.8)
+    for part in partition_tiles(grid, 512, 8, 256):
+        px = 0
+        for _, tids in part:
+            g = [grid[t] for t in tids]
+            px += (max(t[1] for t in g) - min(t[0] for t in g)) * (max(t[3] for t in g) - min(t[2] for t in g))
+        assert px <= 0.18 * n * n

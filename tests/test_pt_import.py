@@ -218,3 +218,16 @@ def test_yolo_shim_accepts_pt(tmp_path, monkeypatch):
     assert m._wpath.endswith(".cyw") and str(tmp_path / "cache") in m._wpath
     m2 = YOLO(str(tmp_path / "best.pt"))                    # second construction reuses the cached conversion
     assert m2._wpath == m._wpath
+
+
+def test_tensor_views_outside_their_storage_are_refused():
+    """A crafted checkpoint must not make the importer read outside a storage blob (negative offset / stride, oversized view)."""
+    import numpy as np
+    from caesar_yolo_amd import pt_import as P
+    st = (np.arange(16, dtype=np.float32), "FloatStorage")
+    assert P._rebuild_tensor(st, 2, (3, 4), (4, 1)).shape == (3, 4)
+    assert P._rebuild_tensor(st, 15, (), ()).shape == ()
+    for off, size, stride in [(-1, (4,), (1,)), (0, (4,), (-1,)), (8, (3, 4), (4, 1)), (0, (5, 4), (4, 1)), (16, (), ()),
+                              (0, (2, 2), (1,)), (0, (-1,), (1,))]:
+        with pytest.raises(P.PtImportError):
+            P._rebuild_tensor(st, off, size, stride)
