@@ -57,6 +57,19 @@ struct StemDownArgs {
     int dbg;                                                            // developer timing switches (CY_SD_DBG): skip a phase
 };
 
+// Fused Bottleneck(64 -> 64 -> 64, 3x3 + 3x3 stride 1, SiLU, optional shortcut) on NHWC fp16 channel slices (bneck64.hip)
+struct BneckArgs {
+    const void* in; int in_ct, in_coff; uint32_t in_bytes;     // input slice (also the residual when shortcut)
+    void* out; int out_ct, out_coff;                            // output slice (same pixel grid)
+    const void* wfrag;                                          // pack_bneck_weights: [conv][block][k-step][lane] x 16 B
+    const float* bias1; const float* bias2;                     // folded biases of cv1 / cv2
+    int B, H, W, shortcut;
+    int dbg;                                                    // developer ablation bits (0 in production)
+};
+constexpr size_t BNECK_WFRAG_BYTES = 2 * 4 * 18 * 1024;
+hipError_t launch_bneck64(const BneckArgs& a, hipStream_t s);
+void pack_bneck_weights(const float* W1, const float* W2, void* dst);      // W: [64][64][3][3] fp32
+
 struct PoolArgs {   // MaxPool2d(5,1,2) on a channel slice of an NHWC buffer, -inf padding
     const void* src; void* dst; int ct, src_coff, dst_coff, C, B, H, W;
 };
@@ -154,6 +167,7 @@ struct PreArgs {
     int* counters;                         // context counters or null: [2] += median-bracket hits, [3] += misses (cy_preproc.hip)
 };
 hipError_t launch_preproc(const PreArgs& a, hipStream_t s);
+hipError_t launch_preproc_planes(const PreArgs& a, hipStream_t s);    // statistics + checks + float64 planes into a.scratch (no packing)
 hipError_t launch_letterbox_pack(const PreArgs& a, hipStream_t s);   // uses scratch/th/tw/new_*/H/W/top/left/out only
 hipError_t launch_mosaic_prepare(float* data, size_t n, int big_endian, hipStream_t s);
 

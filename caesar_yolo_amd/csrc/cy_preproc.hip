@@ -862,6 +862,18 @@ hipError_t launch_preproc(const PreArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// statistics + rejection checks + the preprocessed image itself as float64 planes [B][3][th*tw] in a.scratch (what
+// DataPreprocessor returns to Analyzer.predict, caesar_yolo/evaluation.py:157-161): parity witness and the plotting input
+hipError_t launch_preproc_planes(const PreArgs& a, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(a.status, 0, a.B * sizeof(int), s);
+    if (e != hipSuccess) return e;
+    if (a.nprog > 0) hipLaunchKernelGGL(pre_stats_kernel, dim3(a.B, a.nprog), dim3(NT), 0, s, a);
+    hipLaunchKernelGGL(pre_rowcheck_kernel, dim3(a.B), dim3(256), 0, s, a);
+    int gs = (a.th * a.tw + 255) / 256; if (gs > 1024) gs = 1024;
+    hipLaunchKernelGGL(pre_plane_kernel, dim3(gs, a.B), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_letterbox_pack(const PreArgs& a, hipStream_t s) {
     const int npx = a.H * a.W;
     int gx = (npx + 255) / 256; if (gx > 1024) gx = 1024;

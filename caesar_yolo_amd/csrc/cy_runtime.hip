@@ -13,7 +13,8 @@
 using namespace cy;
 
 struct DevConv { void* w = nullptr; float* bias = nullptr; size_t wbytes = 0; float* stem_w = nullptr; void* w32 = nullptr; size_t w32bytes = 0;
-                 float* dw_w = nullptr; };     // dw_w: depth-wise 3x3 weights [9][C] fp32 (YOLO11)
+                 float* dw_w = nullptr;         // dw_w: depth-wise 3x3 weights [9][C] fp32 (YOLO11)
+                 void* bneck = nullptr; };      // on a bottleneck's cv1: register-fragment weights of the fused cv1+cv2 kernel (bneck64.hip)
 
 struct cy_ctx {
     int device = 0;
@@ -51,6 +52,7 @@ struct cy_ctx {
     bool profiling = false;
     bool split_last = false;                             // the last forward ran as two half-batches (debug reads see only one)
     bool stem_fused_last = false;                        // the last forward ran model.0 + model.1 as one kernel (no model.0 tensor)
+    bool bneck_fused_last = false;                       // ... and 64-channel bottlenecks as one kernel each (their cv1 outputs do not exist)
     int prof_stride = 1; unsigned long fwd_calls = 0;   // profiling on: every prof_stride-th cy_forward call is timed
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
     struct ProfRec { size_t e0, e1; int kind; double flops; int conv; };
@@ -80,7 +82,7 @@ size_t tensor_elems_per_tile(const Plan& p, int H, int W) {
 void free_all(cy_ctx* c) {
     for (auto e : c->ev_pool) hipEventDestroy(e);
     c->ev_pool.clear(); c->ev_used = 0; c->prof.clear();
-    for (auto& d : c->dconv) { if (d.w) hipFree(d.w); if (d.bias) hipFree(d.bias); if (d.stem_w) hipFree(d.stem_w); if (d.w32) hipFree(d.w32); if (d.dw_w) hipFree(d.dw_w); }
+    for (auto& d : c->dconv) { if (d.w) hipFree(d.w); if (d.bias) hipFree(d.bias); if (d.stem_w) hipFree(d.stem_w); if (d.w32) hipFree(d.w32); if (d.dw_w) hipFree(d.dw_w); if (d.bneck) hipFree(d.bneck); }
     c->dconv.clear();
     if (c->ws) hipFree(c->ws);
     c->ws = nullptr;
@@ -141,6 +143,30 @@ int parse_plan_v2(cy_ctx* c, Reader& r, Plan* plan, uint32_t* nconv_out, std::ve
     *nconv_out = nconv;
     plan->ok = true;
     return CY_OK;
+}
+
+// ops[i], ops[i+1] = the two 3x3 convs of a 64-channel Bottleneck (x [+] cv2(cv1(x))) whose intermediate has no other reader:
+// with CY_BNECK_FUSE=1 they run as ONE kernel in the fp16 context (bneck64.hip; off by default: measured slower so far)
+bool bneck_pair(const Plan& p, size_t i) {
+    if (i + 1 >= p.ops.size()) return false;
+    const Op& o = p.ops[i]; const Op& n = p.ops[i + 1];
+    if (o.kind != OPK_CONV || n.kind != OPK_CONV || o.conv < 0 || n.conv < 0 || o.out < 0 || n.out < 0) return false;
+    const ConvDesc& d1 = p.convs[o.conv]; const ConvDesc& d2 = p.convs[n.conv];
+    auto c64 = [](const ConvDesc& d) { return d.k == 3 && d.s == 1 && d.cin == 64 && d.cout == 64 && d.act && d.groups == 1; };
+    if (!c64(d1) || !c64(d2)) return false;
+    if (o.in1 >= 0 || o.up0 || o.res >= 0 || o.c0 != 64 || n.in1 >= 0 || n.up0 || n.c0 != 64) return false;
+    if (n.in0 != o.out || n.in0_coff != o.out_coff) return false;
+    if (p.tensors[o.in0].level != p.tensors[o.out].level || p.tensors[o.in0].level != p.tensors[n.out].level) return false;
+    if (n.res >= 0 && (n.res != o.in0 || n.res_coff != o.in0_coff)) return false;      // the shortcut adds the bottleneck's own input
+    if (n.out == o.in0 && n.out_coff == o.in0_coff) return false;                        // in place: patches would read overwritten halos
+    // the intermediate must be dead after cv2: the next op that touches its tensor (C2f reuses one scratch tensor for all its
+    // bottlenecks) has to overwrite exactly this slice before anything reads it
+    for (size_t j = i + 2; j < p.ops.size(); ++j) {
+        const Op& q = p.ops[j];
+        if (q.in0 == o.out || q.in1 == o.out || q.res == o.out) return false;
+        if (q.out == o.out) return q.out_coff == o.out_coff && q.conv >= 0 && p.convs[q.conv].cout == 64;
+    }
+    return true;
 }
 
 // A CYW2 file carries its own execution plan; it is untrusted data.  Every channel slice an op names must lie inside its
@@ -216,6 +242,7 @@ int upload_weights(cy_ctx* c, const void* buf, size_t nbytes) {
     HIPCHK(c, hipSetDevice(c->device));
     free_all(c);
     c->dconv.resize(nconv);
+    std::vector<const float*> Wsrc(nconv, nullptr);          // folded fp32 weights inside `buf` (for the fused-bottleneck packing below)
     std::vector<char> packed;
     int stem_conv = -1;
     for (auto& o : plan.ops) if (o.kind == OPK_STEM) stem_conv = o.conv;
@@ -238,6 +265,7 @@ int upload_weights(cy_ctx* c, const void* buf, size_t nbytes) {
         const float* W = r.f32((size_t)co * (ci / groups) * k * k);
         const float* b = r.f32(co);
         if (r.bad) return fail(c, CY_ERR_IO, "truncated weight file");
+        Wsrc[i] = W;
         DevConv& dc = c->dconv[i];
         const int cp = (co + 127) / 128 * 128;
         std::vector<float> bias(cp, 0.0f);
@@ -286,6 +314,16 @@ int upload_weights(cy_ctx* c, const void* buf, size_t nbytes) {
     if (v2) {
         const std::string bad = validate_plan(plan);
         if (!bad.empty()) { free_all(c); return fail(c, CY_ERR_IO, "malformed CYW2 plan: " + bad); }
+    }
+    if (c->prec == PREC_F16) {
+        std::vector<char> wf(BNECK_WFRAG_BYTES);
+        for (size_t i = 0; i + 1 < plan.ops.size(); ++i) {
+            if (!bneck_pair(plan, i)) continue;
+            const int c1 = plan.ops[i].conv, c2 = plan.ops[i + 1].conv;
+            pack_bneck_weights(Wsrc[c1], Wsrc[c2], wf.data());
+            HIPCHK(c, hipMalloc(&c->dconv[c1].bneck, wf.size()));
+            HIPCHK(c, hipMemcpy(c->dconv[c1].bneck, wf.data(), wf.size(), hipMemcpyHostToDevice));
+        }
     }
     c->plan = plan; c->names = names;
     // ---- workspace for (max_batch, max_h, max_w)
@@ -551,6 +589,7 @@ static int forward_on(cy_ctx* c, const void* d_netin, int B, int H, int W, float
     };
     c->stem_fused_last = false;
 
+    const int bneck_env = env_knob("CY_BNECK_FUSE", 0);       // off by default (slower than two launches so far, see bneck64.hip); read per call: the parity tests run both forms
     auto run_op = [&](const Op& o, const Op* next, int b0, int Bn, bool* fused) -> int {
         auto tp = [&](int t) -> char* {                    // tensor base for images [b0, b0+Bn)
             char* base = tptr(t);
@@ -558,6 +597,22 @@ static int forward_on(cy_ctx* c, const void* d_netin, int B, int H, int W, float
             return base;
         };
         cur_conv = o.conv;
+        if (bneck_env && c->prec == PREC_F16 && o.kind == OPK_CONV && next && c->dconv[o.conv].bneck &&
+            bneck_pair(p, (size_t)(&o - p.ops.data()))) {
+            const Op& n = *next;
+            const Tensor& ti = p.tensors[o.in0]; const Tensor& to = p.tensors[n.out];
+            BneckArgs a{};
+            a.in = tp(o.in0); a.in_ct = ti.C; a.in_coff = o.in0_coff;
+            a.B = Bn; a.H = H >> ti.level; a.W = W >> ti.level;
+            a.in_bytes = (uint32_t)((size_t)Bn * a.H * a.W * ti.C * es);
+            a.out = tp(n.out); a.out_ct = to.C; a.out_coff = n.out_coff;
+            a.wfrag = c->dconv[o.conv].bneck; a.bias1 = c->dconv[o.conv].bias; a.bias2 = c->dconv[n.conv].bias;
+            a.shortcut = n.res >= 0;
+            HIPCHK(c, launch_bneck64(a, s));
+            prof_done(CONV_NUM_VARIANTS + 4, 2.0 * (2.0 * Bn * a.H * a.W * 64.0 * 64.0 * 9.0));
+            *fused = true; c->bneck_fused_last = true;
+            return CY_OK;
+        }
         if (o.kind == OPK_STEM && next && stem_fusable(o, *next)) {
             const Op& n = *next;
             const Tensor& ti = p.tensors[o.in0]; const Tensor& t1 = p.tensors[o.out]; const Tensor& to = p.tensors[n.out];
@@ -673,12 +728,13 @@ int cy_profile_enable(cy_ctx* c, int on) {
 
 int cy_profile_summary(cy_ctx* c, cy_prof_entry* out, int cap) {
     // one entry per forward kernel variant (conv variants in ConvVariant order, then stem, pool)
-    const int n = CONV_NUM_VARIANTS + 4;
+    const int n = CONV_NUM_VARIANTS + 5;
     if (!c || !out || cap < n) return fail(c, CY_ERR_ARG, "bad arguments");
     HIPCHK(c, hipDeviceSynchronize());
     for (int k = 0; k < n; ++k) {
         memset(&out[k], 0, sizeof(out[k]));
-        static const char* const extra[4] = {"stem_kernel", "pool5_kernel", "dwconv3x3_kernel", "attention_kernel"};
+        static const char* const extra[5] = {"stem_kernel", "pool5_kernel", "dwconv3x3_kernel", "attention_kernel",
+                                             "bneck64_kernel fused 3x3+3x3 64ch bottleneck, weights in registers"};
         const char* nm = k < CONV_NUM_VARIANTS ? conv_variant_name(k) : extra[k - CONV_NUM_VARIANTS];
         strncpy(out[k].kernel, nm, sizeof(out[k].kernel) - 1);
     }
@@ -713,6 +769,8 @@ int cy_debug_read_conv(cy_ctx* c, const char* conv_name, float* h_out, size_t ca
     for (const Op& o : p.ops) {
         if (o.conv < 0 || p.convs[o.conv].name != conv_name) continue;      // pool and attention ops carry no convolution
         if (o.out < 0) return fail(c, CY_ERR_UNSUPPORTED, "head outputs are read from d_pred");
+        if (c->bneck_fused_last && c->dconv[o.conv].bneck && env_knob("CY_BNECK_FUSE", 0))
+            return fail(c, CY_ERR_STATE, "this bottleneck ran fused: its cv1 output was not materialised; unset CY_BNECK_FUSE");
         if (o.kind == OPK_STEM && c->stem_fused_last)
             return fail(c, CY_ERR_STATE, "the stem output was not materialised (fused into the next layer's kernel); set CY_STEM_FUSE=0");
         const Tensor& t = p.tensors[o.out];
@@ -775,6 +833,31 @@ int cy_conv_bn_silu(cy_ctx* c, const void* d_in, int B, int Hi, int Wi, int Cin,
     return CY_OK;
 }
 
+int cy_bottleneck64(cy_ctx* c, const void* d_in, int B, int H, int W, const float* h_w1, const float* h_b1, const float* h_w2,
+                    const float* h_b2, int shortcut, void* d_out, void* stream) {
+    if (!c || !d_in || !h_w1 || !h_b1 || !h_w2 || !h_b2 || !d_out || B < 1 || H < 1 || W < 1) return fail(c, CY_ERR_ARG, "bad arguments");
+    if (c->prec != PREC_F16) return fail(c, CY_ERR_UNSUPPORTED, "the fused bottleneck kernel exists in the fp16 context only");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<char> wf(BNECK_WFRAG_BYTES);
+    pack_bneck_weights(h_w1, h_w2, wf.data());
+    void* dw = nullptr; float* db = nullptr;
+    HIPCHK(c, hipMalloc(&dw, wf.size()));
+    HIPCHK(c, hipMalloc(&db, 128 * sizeof(float)));
+    HIPCHK(c, hipMemcpy(dw, wf.data(), wf.size(), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(db, h_b1, 64 * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(db + 64, h_b2, 64 * sizeof(float), hipMemcpyHostToDevice));
+    BneckArgs a{};
+    a.in = d_in; a.in_ct = 64; a.in_coff = 0; a.in_bytes = (uint32_t)((size_t)B * H * W * 64 * 2);
+    a.out = d_out; a.out_ct = 64; a.out_coff = 0; a.wfrag = dw; a.bias1 = db; a.bias2 = db + 64;
+    a.B = B; a.H = H; a.W = W; a.shortcut = shortcut != 0;
+    hipError_t e = launch_bneck64(a, (hipStream_t)stream);
+    hipError_t e2 = hipStreamSynchronize((hipStream_t)stream);
+    hipFree(dw); hipFree(db);
+    if (e != hipSuccess) return fail(c, CY_ERR_HIP, hipGetErrorString(e));
+    if (e2 != hipSuccess) return fail(c, CY_ERR_HIP, hipGetErrorString(e2));
+    return CY_OK;
+}
+
 int cy_debug_stamps(unsigned long long* out8, int reset) {
     if (!out8) return CY_ERR_ARG;
     if (reset >= 2) debug_read_pre_stamps(out8, reset == 3);       // 2 / 3: the statistics kernel's phase stamps (read / read + reset)
@@ -796,23 +879,15 @@ int cy_preproc_params(cy_ctx* c, double* h_out, int B) {
     return CY_OK;
 }
 
-int cy_preproc(cy_ctx* c, const float* d_mosaic, int MH, int MW, const int* h_tiles, int B, int th, int tw, int imgsz,
-               const cy_preproc_cfg* cfg, void* d_netin, int* d_status, void* stream) {
-    if (!c || !c->loaded) return fail(c, CY_ERR_STATE, "weights not loaded");
-    if (!d_mosaic || !h_tiles || !cfg || !d_netin || !d_status || B < 1 || B > c->cfg.max_batch)
-        return fail(c, CY_ERR_ARG, "bad preproc arguments");
+static int fill_pre_args(cy_ctx* c, const float* d_mosaic, int MH, int MW, const int* h_tiles, int B, int th, int tw,
+                         const cy_preproc_cfg* cfg, int* d_status, PreArgs& a) {
     if (cfg->nprog != 0 && cfg->nprog != 1 && cfg->nprog != 3) return fail(c, CY_ERR_ARG, "nprog must be 0, 1 or 3");
-    cy_letterbox lb;
-    if (cy_letterbox_geometry(th, tw, imgsz, &lb)) return fail(c, CY_ERR_ARG, "bad tile/imgsz");
-    if (lb.H > c->cfg.max_h || lb.W > c->cfg.max_w) return fail(c, CY_ERR_ARG, "letterboxed tile exceeds max_h/max_w of the context");
-    if (B > MAX_PRE_BATCH) return fail(c, CY_ERR_ARG, "at most 256 tiles per cy_preproc call");
-    PreArgs a{};
+    if (B > MAX_PRE_BATCH) return fail(c, CY_ERR_ARG, "at most 256 tiles per preprocessing call");
     for (int b = 0; b < B; ++b) {
         a.txy[2 * b] = h_tiles[2 * b]; a.txy[2 * b + 1] = h_tiles[2 * b + 1];
         if (h_tiles[2 * b] < 0 || h_tiles[2 * b + 1] < 0 || h_tiles[2 * b] + tw > MW || h_tiles[2 * b + 1] + th > MH)
             return fail(c, CY_ERR_ARG, "tile outside the mosaic");
     }
-    hipStream_t s = (hipStream_t)stream;
     a.mosaic = d_mosaic; a.MH = MH; a.MW = MW; a.B = B; a.th = th; a.tw = tw;
     a.nprog = cfg->nprog;
     for (int i = 0; i < 3; ++i) {
@@ -831,12 +906,40 @@ int cy_preproc(cy_ctx* c, const float* d_mosaic, int MH, int MW, const int* h_ti
         }
     }
     a.params = c->S().pre_params; a.histeq = c->S().pre_histeq; a.status = d_status; a.counters = c->counters;
+    return CY_OK;
+}
+
+int cy_preproc(cy_ctx* c, const float* d_mosaic, int MH, int MW, const int* h_tiles, int B, int th, int tw, int imgsz,
+               const cy_preproc_cfg* cfg, void* d_netin, int* d_status, void* stream) {
+    if (!c || !c->loaded) return fail(c, CY_ERR_STATE, "weights not loaded");
+    if (!d_mosaic || !h_tiles || !cfg || !d_netin || !d_status || B < 1 || B > c->cfg.max_batch)
+        return fail(c, CY_ERR_ARG, "bad preproc arguments");
+    cy_letterbox lb;
+    if (cy_letterbox_geometry(th, tw, imgsz, &lb)) return fail(c, CY_ERR_ARG, "bad tile/imgsz");
+    if (lb.H > c->cfg.max_h || lb.W > c->cfg.max_w) return fail(c, CY_ERR_ARG, "letterboxed tile exceeds max_h/max_w of the context");
+    PreArgs a{};
+    int rc = fill_pre_args(c, d_mosaic, MH, MW, h_tiles, B, th, tw, cfg, d_status, a);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
     a.out = d_netin; a.out_prec = c->prec; a.H = lb.H; a.W = lb.W; a.top = lb.top; a.left = lb.left;
     a.new_h = lb.new_h; a.new_w = lb.new_w;
     const bool resize = (lb.new_h != th) || (lb.new_w != tw);
     if (resize && (size_t)B * 3 * th * tw > c->pre_scratch_elems) return fail(c, CY_ERR_ARG, "resize scratch too small");
     a.scratch = resize ? c->S().pre_scratch : nullptr;
     HIPCHK(c, launch_preproc(a, s));
+    return CY_OK;
+}
+
+int cy_preproc_planes(cy_ctx* c, const float* d_mosaic, int MH, int MW, const int* h_tiles, int B, int th, int tw,
+                      const cy_preproc_cfg* cfg, double* d_planes, int* d_status, void* stream) {
+    if (!c || !c->loaded) return fail(c, CY_ERR_STATE, "weights not loaded");
+    if (!d_mosaic || !h_tiles || !cfg || !d_planes || !d_status || B < 1 || B > c->cfg.max_batch || th < 1 || tw < 1)
+        return fail(c, CY_ERR_ARG, "bad preproc arguments");
+    PreArgs a{};
+    int rc = fill_pre_args(c, d_mosaic, MH, MW, h_tiles, B, th, tw, cfg, d_status, a);
+    if (rc) return rc;
+    a.scratch = d_planes;
+    HIPCHK(c, launch_preproc_planes(a, (hipStream_t)stream));
     return CY_OK;
 }
 

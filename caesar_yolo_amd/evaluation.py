@@ -3,8 +3,10 @@
 `Analyzer(model, config).predict(image, image_id, header, xmin, ymin)` keeps the reference's contract: 0 / -1 return,
 results in `.bboxes_final / .scores_final / .class_ids_final / .labels_final / .results`; the work between the image and
 the merged boxes (3-channel cube, preprocessing, rejection checks, model call, score filter + IoU graph merge:
-evaluation.py:146-346) is one `cy_detect_tiles` call with the frame as a single tile.  Plotting and DS9 output are out
-of scope."""
+evaluation.py:146-346) is one `cy_detect_tiles` call with the frame as a single tile.  The optional outputs are mirrored
+too: out_<id>.json (:472-482), the DS9 region file (:487-548, Analyzer's own colour map), the plot (`draw_results`,
+:351-411, matplotlib) and the preprocessed image as FITS (`write_fits`, :550-554); plot and FITS show the PREPROCESSED
+image, which is fetched from the device (`cy_preproc_planes`) only when one of them is asked for."""
 import json
 import logging
 import numpy as np
@@ -31,6 +33,15 @@ class Analyzer(object):
         self.outfile_json = ""
         self.write_to_ds9 = config.get('save_region', True)      # caesar_yolo/evaluation.py:97
         self.outfile_ds9 = ""
+        self.draw = config.get('draw_plot', False)                # :93-95
+        self.save_plots = config.get('save_plot', False)
+        self.draw_class_label_in_caption = config.get('draw_class_label_in_caption', True)
+        self.outfile = ""
+        self.save_img = config.get('save_img', False)            # :98
+        self.outfile_img = ""
+        self.image = None                                         # (H,W,3) float64 preprocessed image, when a plot / FITS was asked for
+        self.class_color_map = {'bkg': (0, 0, 0), 'spurious': (1, 0, 0), 'compact': (0, 0, 1), 'extended': (1, 1, 0),
+                                'extended-multisland': (1, 0.647, 0), 'flagged': (0, 0, 0)}       # :100-107
         self.obj_name_tag = ""
         self.image_id = -1
         self.image_xmin = self.image_ymin = 0
@@ -68,6 +79,9 @@ class Analyzer(object):
         if st == 2:
             logger.warning("Input image pixels have the same value in one of the first rows, no prediction made.")
             return -1
+        if self.draw or self.save_img:
+            planes, _ = det.preproc_planes(mosaic, [(0, 0)], ny, nx, cfg)
+            self.image = np.ascontiguousarray(planes[0].cpu().numpy().transpose(1, 2, 0))
         dd = d[0, :int(cnt[0])].cpu().numpy()
         self.bboxes_final = [dd[i, :4].copy() for i in range(dd.shape[0])]
         self.scores_final = [dd[i, 4] for i in range(dd.shape[0])]
@@ -75,15 +89,63 @@ class Analyzer(object):
         self.labels_final = [self.class_names[c] for c in self.class_ids_final]
         self.results = {"image_id": self.image_id,
                         "objs": objs_from_detections(dd, self.class_names, nx, ny, xmin, ymin, self.obj_name_tag)}
+        if self.draw:                                             # caesar_yolo/evaluation.py:203-210
+            self.draw_results(self.outfile or ('out_' + str(self.image_id) + '.png'))
         if self.write_to_json:
             self.write_json_results(self.outfile_json or ('out_' + str(self.image_id) + '.json'))
         if self.write_to_ds9:                                     # caesar_yolo/evaluation.py:228-234
             self.write_ds9_regions(self.outfile_ds9 or ('out_' + str(self.image_id) + '.reg'))
+        if self.save_img:                                         # :237-243
+            self.write_fits(self.outfile_img or ('out_' + str(self.image_id) + '.fits'))
         return 0
 
     def write_ds9_regions(self, outfile):
         from . import utils
-        utils.write_ds9_regions(outfile, self.results.get("objs", []), merged_tag=False)
+        utils.write_ds9_regions(outfile, self.results.get("objs", []), color_map=utils.CLASS_COLOR_MAP_DS9_FRAME, merged_tag=False)
+
+    def write_fits(self, outfile):
+        """caesar_yolo/evaluation.py:550-554: channel 0 of the preprocessed image, float64."""
+        from . import utils
+        logger.info("Saving 2D image to file %s ..." % outfile)
+        utils.write_fits_image(outfile, self.image[:, :, 0], bitpix=-64)
+
+    def draw_results(self, outfile):
+        """caesar_yolo/evaluation.py:351-411: the preprocessed image with one rectangle + caption per final detection; written
+        to `outfile` when save_plots is set, shown otherwise (needs matplotlib; a missing matplotlib is a warning, not an error)."""
+        try:
+            import matplotlib
+            if self.save_plots:
+                matplotlib.use("Agg")
+            import matplotlib.pyplot as plt
+            from matplotlib import patches
+        except Exception as e:
+            logger.warning("Cannot draw results: matplotlib is not available (%s)" % str(e))
+            return
+        img = self.image.copy()
+        if img.max() == 1:
+            img *= 255.
+        img = img.astype(np.uint32)
+        fig, ax = plt.subplots(1, figsize=(16, 16))
+        height, width = img.shape[:2]
+        ax.set_ylim(height + 2, -2)
+        ax.set_xlim(-2, width + 2)
+        ax.axis('off')
+        ax.imshow(img)
+        for bbox, score, label in zip(self.bboxes_final, self.scores_final, self.labels_final):
+            color = self.class_color_map.get(label, (1, 1, 1))
+            x1, y1, x2, y2 = (float(v) for v in bbox)
+            ax.add_patch(patches.Rectangle((x1, y1), x2 - x1, y2 - y1, linewidth=2, alpha=0.7, linestyle="solid", edgecolor=color,
+                                           facecolor='none'))
+            if self.draw_class_label_in_caption:
+                ax.text(x1, y1 + 8, "{} {:.2f}".format(label, score), color=color, size=20, backgroundcolor="none")
+            else:
+                ax.text(x1 + (x2 - x1) / 2 - 4, y1 - 1, "{:.2f}".format(score), color="darkturquoise", size=30, backgroundcolor="none")
+        logger.info("Write plot to file %s ..." % outfile)
+        if self.save_plots:
+            fig.savefig(outfile)
+            plt.close(fig)
+        else:
+            plt.show()
 
     def write_json_results(self, outfile):
         if not self.results:

@@ -158,13 +158,14 @@ class TileEngine(object):
         self.my = parts[rank]
         n_my = self.counts[rank]
         # launch plan, built once: (th, tw, B, origins, first row, device image the origins refer to)
-        self.plan, row = [], 0
+        self.plan, row, self._origins = [], 0, {}
         for (th, tw), tids in self.my:
             img, ox, oy = self.mosaic, 0, 0
             if isinstance(self.mosaic, MosaicSource) and tids:
                 g = [self.grid[t] for t in tids]
                 img, ox, oy = self.mosaic.region(detector, min(t[0] for t in g), max(t[1] for t in g),
                                                  min(t[2] for t in g), max(t[3] for t in g))
+            self._origins[id(img)] = (ox, oy)
             nb = (len(tids) + self.batch - 1) // self.batch        # equal-sized batches (198 tiles -> 50,50,49,49, not 64,64,64,6)
             i = 0
             for k in range(nb):
@@ -186,6 +187,10 @@ class TileEngine(object):
         self.tid_all = torch.tensor(order if order else [0], dtype=torch.float32, device=dev)
         self.n_my = n_my
         self.gathered = None
+
+    def origin_of(self, img):
+        """(x, y) of the mosaic pixel at [0, 0] of a device image of the launch plan (regions are rebased)."""
+        return self._origins.get(id(img), (0, 0))
 
     def run_local(self):
         """Enqueue every batch of this rank's tiles (software-pipelined inside the library); results stay on device."""
@@ -407,7 +412,7 @@ class SFinder(object):
         if self.config.get('use_multi_gpu') and len(devs) > rank:
             return devs[rank]                      # caesar_yolo/inference.py:207-210: device = devices[procId]
         d = devs[0]
-        return int(os.environ.get("LOCAL_RANK", "0")) if d in ("cpu", "") else d
+        return int(os.environ.get("LOCAL_RANK", "0")) if d == "" else d      # 'cpu': model._dev_index picks this rank's GPU and warns
 
     def _pre_cfg(self):
         dp = self.config.get('preprocess_fcn')
@@ -417,42 +422,41 @@ class SFinder(object):
         c = self.config
         return c['score_thr'], c['iou_thr'], c['merge_overlap_iou_thr_soft'], c['merge_overlap_iou_thr_hard']
 
-    # ---- serial: one frame (reference :485-552 + Analyzer.predict)
+    # ---- serial: one frame (reference :485-552: read the image, hand it to an Analyzer)
     def run(self):
-        m = self._load_mosaic()
-        if m is None:
-            logger.error("Failed to read image %s!" % self.config['image_path'])
+        from .evaluation import Analyzer
+        path = self.config['image_path']
+        if os.path.splitext(path)[1] != '.fits':
+            logger.error("Only FITS images are supported on the HIP path")
             return -1
-        det, mosaic = m
-        conf, iou, soft, hard = self._thr()
-        try:
-            d, cnt, status = det.detect_tiles(mosaic, [(0, 0)], self.ny, self.nx, self.config['img_size'], self._pre_cfg(),
-                                              conf, iou, soft, hard)
-            torch.cuda.synchronize(det.tdev)
-        except L.CyError as e:
-            logger.warning("Model prediction failed (err=%s)..." % str(e))
+        res = utils.read_fits_image(path)
+        if res is None:
+            logger.error("Failed to read image %s!" % path)
             return -1
-        if int(status[0]) != 0:
-            logger.warning("Input image rejected by preprocessing (status %d), no prediction made." % int(status[0]))
+        data, self.header = res
+        self.image_id = utils.image_id_of(path)
+        self.ny, self.nx = data.shape
+        self._beam_info()
+        analyzer = Analyzer(self.model, self.config)
+        analyzer.device = self._device()
+        analyzer.outfile_json = self.outfile_json
+        if analyzer.predict(image=data, image_id=self.image_id, header=self.header) < 0:
+            logger.error("Failed to run model prediction on image %s!" % path)
             return -1
-        dd = d[0, :int(cnt[0])].cpu().numpy()
-        self.results = {"image_id": self.image_id, "objs": objs_from_detections(dd, self.model.names, self.nx, self.ny)}
-        if self.write_to_json:
-            out = self.outfile_json or ('out_' + str(self.image_id) + '.json')
-            with open(out, 'w') as fp:
-                json.dump(self.results, fp, indent=2, sort_keys=True)
-        if self.write_to_ds9:                                     # caesar_yolo/evaluation.py:228-234
-            utils.write_ds9_regions(self.outfile_ds9 or ('out_' + str(self.image_id) + '.reg'), self.results["objs"],
-                                    merged_tag=False)
+        self.results = analyzer.results
+        if not analyzer.bboxes_final:
+            logger.info("No object detected in image %s ..." % path)
+        else:
+            logger.info("#%d objects found in image %s ..." % (len(analyzer.bboxes_final), path))
         return 0
 
-    def _write_tile_outputs(self, eng, mosaic):
-        """--save_tile_catalog / --save_tile_region / --save_tile_img (caesar_yolo/inference.py:330-350, :220-229,
-        :1020-1022): one catalog_<id>_tid<N>.json / .reg / timg_<id>_tid<N>.fits per tile that ran.  The reference writes
-        them from each worker's Analyzer; here rank 0 writes the same files after the gather."""
+    def _write_tile_outputs(self, eng):
+        """--save_tile_catalog / --save_tile_region (caesar_yolo/inference.py:330-350, :220-227, :1020-1021): one
+        catalog_<id>_tid<N>.json / .reg per tile that ran.  The reference writes them from each worker's Analyzer; here rank 0
+        writes the same files after the gather (Analyzer's colour map for the regions)."""
         c = self.config
-        sj, sr, si = c.get('save_tile_catalog', False), c.get('save_tile_region', False), c.get('save_tile_img', False)
-        if not (sj or sr or si):
+        sj, sr = c.get('save_tile_catalog', False), c.get('save_tile_region', False)
+        if not (sj or sr):
             return
         res = eng.tile_results(self.model.names, self.image_id)
         for tid, r in sorted(res.items()):
@@ -461,12 +465,24 @@ class SFinder(object):
                 with open('catalog_' + stem + '.json', 'w') as fp:
                     json.dump(r, fp, indent=2, sort_keys=True)
             if sr:
-                utils.write_ds9_regions('catalog_' + stem + '.reg', r["objs"], merged_tag=False)
-            if si and isinstance(mosaic, MosaicSource):
-                x0, x1, y0, y1 = eng.grid[tid]
-                tile = np.array(mosaic.host[y0:y1, x0:x1], dtype=np.float32)
-                tile[~np.isfinite(tile)] = 0                       # read_fits_crop value semantics (utils.py:394)
-                utils.write_fits_image('timg_' + stem + '.fits', tile)
+                utils.write_ds9_regions('catalog_' + stem + '.reg', r["objs"], color_map=utils.CLASS_COLOR_MAP_DS9_FRAME,
+                                        merged_tag=False)
+
+    def _write_tile_images(self, eng):
+        """--save_tile_img (:228-229 -> Analyzer.write_fits, evaluation.py:550-554): timg_<id>_tid<N>.fits = channel 0 of the
+        PREPROCESSED tile, float64.  Every rank writes its own tiles (it holds their pixels), like the reference's workers;
+        tiles the pipeline rejected write nothing."""
+        if not self.config.get('save_tile_img', False):
+            return
+        grid_id = {(g[0], g[2], g[3] - g[2], g[1] - g[0]): t for t, g in enumerate(eng.grid)}
+        for th, tw, B, xy, row, img in eng.plan:
+            planes, status = eng.det.preproc_planes(img, xy, th, tw, eng.pre_cfg)
+            ch0, status = planes[:, 0].cpu().numpy(), status.cpu().numpy()
+            ox, oy = eng.origin_of(img)
+            for b, (x, y) in enumerate(xy):
+                if status[b] == 0:
+                    tid = grid_id[(x + ox, y + oy, th, tw)]
+                    utils.write_fits_image('timg_' + str(self.image_id) + '_tid' + str(tid) + '.fits', ch0[b], bitpix=-64)
 
     # ---- tiled (reference :578-658)
     def run_parallel(self):
@@ -498,8 +514,9 @@ class SFinder(object):
             return -1
         eng.run_local()
         eng.gather()
+        self._write_tile_images(eng)
         if rank == 0:
-            self._write_tile_outputs(eng, mosaic)
+            self._write_tile_outputs(eng)
             src, self.stats = eng.catalog(self.model.names)
             self.sources = {"sources": src}
             if self.write_to_json:

@@ -16,8 +16,8 @@ F16, F32 = 0, 1
 EXPORTS = [
     "cy_create", "cy_destroy", "cy_last_error", "cy_load_weights", "cy_load_weights_mem", "cy_num_classes",
     "cy_class_name", "cy_plan_num_convs", "cy_plan_conv_desc", "cy_letterbox_geometry", "cy_num_anchors",
-    "cy_pred_elems", "cy_profile_enable", "cy_profile_summary", "cy_profile_layers", "cy_mosaic_prepare", "cy_letterbox_pack", "cy_preproc", "cy_preproc_params", "cy_forward", "cy_debug_read_conv",
-    "cy_decode_nms", "cy_debug_stamps", "cy_debug_cand_counts", "cy_iou_merge", "cy_detect_tiles", "cy_detect_flush", "cy_detect_counters", "cy_conv_bn_silu", "cy_make_tile_records",
+    "cy_pred_elems", "cy_profile_enable", "cy_profile_summary", "cy_profile_layers", "cy_mosaic_prepare", "cy_letterbox_pack", "cy_preproc", "cy_preproc_planes", "cy_preproc_params", "cy_forward", "cy_debug_read_conv",
+    "cy_decode_nms", "cy_debug_stamps", "cy_debug_cand_counts", "cy_iou_merge", "cy_detect_tiles", "cy_detect_flush", "cy_detect_counters", "cy_conv_bn_silu", "cy_bottleneck64", "cy_make_tile_records",
     "cy_merge_edge_sources",
 ]
 
@@ -89,6 +89,7 @@ def load():
         "cy_mosaic_prepare": (C.c_int, [vp, vp, C.c_size_t, C.c_int, vp]),
         "cy_preproc": (C.c_int, [vp, vp, C.c_int, C.c_int, ip, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.POINTER(cy_preproc_cfg), vp, vp, vp]),
+        "cy_preproc_planes": (C.c_int, [vp, vp, C.c_int, C.c_int, ip, C.c_int, C.c_int, C.c_int, C.POINTER(cy_preproc_cfg), vp, vp, vp]),
         "cy_preproc_params": (C.c_int, [vp, dp, C.c_int]),
         "cy_letterbox_pack": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
         "cy_forward": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
@@ -108,6 +109,7 @@ def load():
         "cy_detect_counters": (C.c_int, [vp, C.POINTER(C.c_longlong), C.c_int]),
         "cy_conv_bn_silu": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp, C.c_int, C.c_int, C.c_int,
                                       C.c_int, vp, vp, vp]),
+        "cy_bottleneck64": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, fp, fp, fp, fp, C.c_int, vp, vp]),
         "cy_make_tile_records": (C.c_int, [fp, ip, C.c_int, ip, C.c_int, dp]),
         "cy_merge_edge_sources": (C.c_int, [dp, C.c_int, ip, C.c_int, dp]),
     }

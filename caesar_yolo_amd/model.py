@@ -114,6 +114,16 @@ class HipDetector(object):
                                       C.byref(cfg), self._p(netin), self._p(status), self._stream()))
         return netin, status, lb
 
+    def preproc_planes(self, mosaic, tiles_xy, th, tw, cfg):
+        """-> (float64 [B,3,th,tw] preprocessed images in image channel order, status [B]) on device."""
+        B = len(tiles_xy)
+        planes = torch.empty((B, 3, th, tw), dtype=torch.float64, device=self.tdev)
+        status = torch.empty((B,), dtype=torch.int32, device=self.tdev)
+        t = (C.c_int * (2 * B))(*[int(v) for xy in tiles_xy for v in xy])
+        self._chk(self.lib.cy_preproc_planes(self.ctx, self._p(mosaic), mosaic.shape[0], mosaic.shape[1], t, B, th, tw,
+                                             C.byref(cfg), self._p(planes), self._p(status), self._stream()))
+        return planes, status
+
     def preproc_params(self, B):
         out = np.zeros((B, 3, L.CY_MAX_STAGES, 4), np.float64)
         self._chk(self.lib.cy_preproc_params(self.ctx, out.ctypes.data_as(C.POINTER(C.c_double)), B))
@@ -201,6 +211,16 @@ class HipDetector(object):
         if flush:
             self.flush()
         return det, cnt, status
+
+    def bottleneck64(self, x_nhwc, w1, b1, w2, b2, shortcut=True):
+        """Fused 64-channel Bottleneck (kernel-level test entry): x [B,H,W,64] fp16 -> [B,H,W,64]."""
+        B, H, Wd, Cin = x_nhwc.shape
+        out = torch.empty_like(x_nhwc)
+        arrs = [np.ascontiguousarray(v, np.float32) for v in (w1, b1, w2, b2)]
+        ptr = [v.ctypes.data_as(C.POINTER(C.c_float)) for v in arrs]
+        self._chk(self.lib.cy_bottleneck64(self.ctx, self._p(x_nhwc), B, H, Wd, ptr[0], ptr[1], ptr[2], ptr[3], int(bool(shortcut)),
+                                           self._p(out), self._stream()))
+        return out
 
     def conv_bn_silu(self, x_nhwc, w, b, k, s, act=True, res=None):
         B, Hi, Wi, Cin = x_nhwc.shape

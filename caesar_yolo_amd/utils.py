@@ -111,11 +111,12 @@ def read_fits_image(filename):
     return data, hdr
 
 
-def write_fits_image(filename, data, cards=None):
-    """Minimal BITPIX -32 writer (synthetic mosaics for the benchmark and tests)."""
+def write_fits_image(filename, data, cards=None, bitpix=-32):
+    """Minimal FITS image writer, BITPIX -32 (synthetic mosaics for the benchmark and tests) or -64 (the preprocessed
+    float64 image the reference's Analyzer.write_fits saves, caesar_yolo/evaluation.py:550-554)."""
     data = np.asarray(data)
     ny, nx = data.shape
-    cards_all = [("SIMPLE", True), ("BITPIX", -32), ("NAXIS", 2), ("NAXIS1", nx), ("NAXIS2", ny)] + list(cards or [])
+    cards_all = [("SIMPLE", True), ("BITPIX", bitpix), ("NAXIS", 2), ("NAXIS1", nx), ("NAXIS2", ny)] + list(cards or [])
     txt = ""
     for k, v in cards_all:
         if isinstance(v, bool):
@@ -131,7 +132,7 @@ def write_fits_image(filename, data, cards=None):
     txt = txt.ljust((len(txt) + 2879) // 2880 * 2880)
     with open(filename, "wb") as fp:
         fp.write(txt.encode("ascii"))
-        payload = data.astype(">f4").tobytes()
+        payload = data.astype(">f8" if bitpix == -64 else ">f4").tobytes()
         fp.write(payload)
         fp.write(b"\0" * ((-len(payload)) % 2880))
 
@@ -139,7 +140,10 @@ def write_fits_image(filename, data, cards=None):
 # --------------------------------------------------------------------------------------------- DS9 regions
 CLASS_COLOR_MAP_DS9 = {'bkg': "black", 'spurious': "red", 'compact': "blue", 'extended': "green",
                        'extended-multisland': "yellow", 'flagged': "black", 'diffuse': "magenta"}
-# (caesar_yolo/inference.py:334-342, evaluation.py class_color_map_ds9)
+# (SFinder's map, caesar_yolo/inference.py:334-342: the tiled catalog's regions)
+CLASS_COLOR_MAP_DS9_FRAME = {'bkg': "black", 'spurious': "red", 'compact': "blue", 'extended': "green",
+                             'extended-multisland': "orange", 'flagged': "magenta"}
+# (Analyzer's map, caesar_yolo/evaluation.py:108-115: single frames and per-tile regions)
 
 
 def ds9_region_lines(objs, color_map=None, merged_tag=True):

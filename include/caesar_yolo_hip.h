@@ -88,6 +88,11 @@ int cy_mosaic_prepare(cy_ctx* ctx, float* d_data, size_t n, int big_endian, void
  * d_netin: [B][H][W][4] (fp16 or fp32 per context precision); d_status[B]: 0 ok, 1 pipeline returned None, 2 row check */
 int cy_preproc(cy_ctx* ctx, const float* d_mosaic, int MH, int MW, const int* h_tiles, int B, int th, int tw,
                int imgsz, const cy_preproc_cfg* cfg, void* d_netin, int* d_status, void* stream);
+/* the same statistics and rejection checks, but the output is the preprocessed image itself, d_planes [B][3][th*tw] float64
+ * in image channel order = what `DataPreprocessor.__call__` hands back to Analyzer.predict (caesar_yolo/evaluation.py:157-161,
+ * before the model's LetterBox): full-precision parity witness, and the picture Analyzer.draw_results plots (:351-411) */
+int cy_preproc_planes(cy_ctx* ctx, const float* d_mosaic, int MH, int MW, const int* h_tiles, int B, int th, int tw,
+                      const cy_preproc_cfg* cfg, double* d_planes, int* d_status, void* stream);
 /* witness for parity tests: solved per-stage parameters of the last cy_preproc call, [B][3][CY_MAX_STAGES][4] doubles */
 int cy_preproc_params(cy_ctx* ctx, double* h_out, int B);
 
@@ -146,6 +151,12 @@ int cy_detect_counters(cy_ctx* ctx, long long* out4, int reset);
  * d_res optional residual [B][Ho][Wo][Cout] */
 int cy_conv_bn_silu(cy_ctx* ctx, const void* d_in, int B, int Hi, int Wi, int Cin, const float* h_w, const float* h_b,
                     int Cout, int k, int s, int act, const void* d_res, void* d_out, void* stream);
+
+/* one fused Bottleneck(64, 64, shortcut) = x [+] SiLU(cv2(SiLU(cv1(x)))) with two folded 3x3 convs, as the forward runs the
+ * stride-4 C2f blocks of yolov8l in the fp16 context (kernel-level parity tests).  d_in, d_out [B][H][W][64] fp16;
+ * h_w1, h_w2 [64][64][3][3], h_b1, h_b2 [64] fp32 */
+int cy_bottleneck64(cy_ctx* ctx, const void* d_in, int B, int H, int W, const float* h_w1, const float* h_b1,
+                    const float* h_w2, const float* h_b2, int shortcut, void* d_out, void* stream);
 
 /* ---- catalog records and cross-tile merge (host code, no GPU) --------------------------------- */
 /* Analyzer.make_json_results (caesar_yolo/evaluation.py:418-469: int() truncation, tile-local edge rule, tile origin)

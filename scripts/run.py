@@ -150,12 +150,11 @@ def main(argv=None):
               'score_thr': args.scoreThr, 'merge_overlap_iou_thr_soft': args.merge_overlap_iou_thr_soft,
               'merge_overlap_iou_thr_hard': args.merge_overlap_iou_thr_hard, 'outfile': args.detect_outfile,
               'outfile_json': args.detect_outfile_json, 'save_region': True, 'tile_batch': args.tile_batch,
+              'draw_plot': args.draw_plots, 'draw_class_label_in_caption': args.draw_class_label_in_caption,
+              'save_plot': args.save_plots,
               'save_tile_catalog': args.save_tile_catalog, 'save_tile_region': args.save_tile_region,
               'save_tile_img': args.save_tile_img,
               'precision': args.precision})
-    if args.draw_plots or args.save_plots or args.draw_class_label_in_caption:
-        logger.warning("--draw_plots / --save_plots / --draw_class_label_in_caption: plotting is not part of this build "
-                       "(SURVEY.md section 8 f4), the flags are ignored")
     model = YOLO(args.weights, precision=args.precision, max_batch=args.tile_batch if args.split_img_in_tiles else 1,
                  max_imgsz=max(args.imgsize, 32))
     sfinder = SFinder(model, C)

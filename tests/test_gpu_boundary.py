@@ -105,3 +105,31 @@ def test_counters_report_candidate_overflow_and_degenerate_boxes():
     d, cnt, st = full.detect_tiles(mosaic, [(0, 0)], 192, 192, 192, cfg, 0.0, IOU, SOFT, HARD)
     assert full.counters()["cand_overflow_tiles"] == 0 and int(cnt[0]) > 0
     full.close()
+
+
+def test_analyzer_plot_and_preprocessed_fits(tmp_path, monkeypatch):
+    """--draw_plots --save_plots / save_img (caesar_yolo/evaluation.py:203-210, :237-243, :351-411, :550-554): a PNG of the
+    preprocessed image with the final boxes, and channel 0 of the preprocessed image as a float64 FITS equal to the
+    reference-pinned oracle's output."""
+    from caesar_yolo_amd.model import YOLO
+    from caesar_yolo_amd.evaluation import Analyzer
+    from caesar_yolo_amd.config import CONFIG
+    from caesar_yolo_amd import preprocessing as PP, utils
+    monkeypatch.chdir(tmp_path)
+    img, cube = _galaxy_cube()
+    model = YOLO(seeded_weights()[0], precision="fp32", max_batch=1, max_imgsz=640)
+    c = dict(CONFIG)
+    c.update(img_size=640, preprocess_fcn=PP.DataPreprocessor([PP.ZScaleTransformer([0.25] * 3), PP.MinMaxNormalizer(0, 255)]),
+             score_thr=CONF, iou_thr=IOU, merge_overlap_iou_thr_soft=SOFT, merge_overlap_iou_thr_hard=HARD, devices=["0"],
+             draw_plot=True, save_plot=True, draw_class_label_in_caption=True, save_img=True, save_region=True)
+    an = Analyzer(model, c)
+    assert an.predict(img, image_id="galaxy0001") == 0 and len(an.bboxes_final) > 0
+    assert os.path.getsize(tmp_path / "out_galaxy0001.png") > 10000
+    assert an.image.shape == (132, 132, 3)
+    np.testing.assert_allclose(an.image, cube, rtol=1e-10, atol=1e-12)
+    data, hdr = utils.get_fits_header(str(tmp_path / "out_galaxy0001.fits"))[0], None
+    assert data["BITPIX"] == -64 and data["NAXIS1"] == 132 and data["NAXIS2"] == 132
+    raw = np.memmap(str(tmp_path / "out_galaxy0001.fits"), dtype=">f8", mode="r", offset=2880, shape=(132, 132))
+    np.testing.assert_allclose(np.asarray(raw), cube[:, :, 0], rtol=1e-10, atol=1e-12)
+    reg = open(tmp_path / "out_galaxy0001.reg").read().splitlines()
+    assert reg[1] == "image" and len(reg) == 2 + len(an.bboxes_final)

@@ -120,3 +120,29 @@ def test_conv_random_geometry_fp16(seed, monkeypatch):
     err = float((got - y).abs().max())
     assert err <= 4e-3 * scale, "B%d %dx%d %d->%d k%d s%d act%d res%d: max abs err %.3e (scale %.2f)" % (
         B, H, Wd, Cin, Cout, k, s, act, use_res, err, scale)
+
+
+@pytest.mark.parametrize("B,H,W,shortcut", [(2, 16, 32, True), (3, 40, 70, True), (1, 8, 32, False), (5, 128, 128, True), (2, 13, 9, False),
+                                            (300, 24, 40, True)])
+def test_fused_bottleneck64(B, H, W, shortcut):
+    """bneck64_kernel (two 3x3 64->64 convs + SiLU + shortcut in one launch, cv1's output kept in LDS as fp16) against the same
+    two steps in torch: fp16-rounded input / weights, fp32 accumulation, the intermediate rounded to fp16 as the unfused path
+    stores it.  Covers ragged patches (8 x 32 px), borders (zero padding of BOTH convs), batches above the persistent grid."""
+    det = detector("fp16")
+    g = torch.Generator().manual_seed(1000 * B + 10 * H + W)
+    x = torch.randn((B, 64, H, W), generator=g).half().float()
+    w1 = (torch.randn((64, 64, 3, 3), generator=g) / 24.0).half().float()
+    w2 = (torch.randn((64, 64, 3, 3), generator=g) / 24.0).half().float()
+    b1 = torch.randn((64,), generator=g) * 0.1
+    b2 = torch.randn((64,), generator=g) * 0.1
+    t = F.silu(F.conv2d(x, w1, b1, padding=1)).half().float()
+    ref = F.silu(F.conv2d(t, w2, b2, padding=1))
+    if shortcut:
+        ref = ref + x
+    xd = x.permute(0, 2, 3, 1).contiguous().half().cuda()
+    got = det.bottleneck64(xd, w1.numpy(), b1.numpy(), w2.numpy(), b2.numpy(), shortcut)
+    torch.cuda.synchronize()
+    got = got.float().cpu().permute(0, 3, 1, 2)
+    sc = max(1.0, float(ref.abs().max()))
+    err = float((got - ref).abs().max())
+    assert err <= 4e-3 * sc, "max abs err %.3e (scale %.2f)" % (err, sc)

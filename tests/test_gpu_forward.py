@@ -43,6 +43,8 @@ TAPS = ["model.0", "model.1", "model.2.cv1", "model.2.m.2.cv1", "model.12.m.0.cv
     ("fp16", 6e-2, 3e-2, {"CY_DIRECT_MIN_BLOCKS": "1"}), ("fp16", 6e-2, 3e-2, {"CY_DIRECT_MIN_BLOCKS": "-1"}),
     # model.0 + model.1 as one kernel (default from 256 workgroups on); the model.0 tensor does not exist then
     ("fp16", 6e-2, 3e-2, {"CY_STEM_FUSE": "2"}),
+    # the 64-channel bottlenecks of model.2 as ONE kernel each (cv1's output stays in LDS; opt-in, default is two launches)
+    ("fp16", 6e-2, 3e-2, {"CY_BNECK_FUSE": "1"}),
     # kernel selection that sees the real batch of 2 (the default evaluates every threshold as for 256 tiles)
     ("fp16", 6e-2, 3e-2, {"CY_BATCH_INVARIANT": "0"}), ("fp16", 6e-2, 3e-2, {"CY_BATCH_INVARIANT": "0", "CY_DIRECT_MIN_BLOCKS": "1"})])
 def test_forward_matches_oracle(prec, tol_raw, tol_tap, env, monkeypatch):
@@ -57,6 +59,10 @@ def test_forward_matches_oracle(prec, tol_raw, tol_tap, env, monkeypatch):
         ref = taps[name]
         if name == "model.0" and prec == "fp16" and env.get("CY_BATCH_INVARIANT") != "0" and env.get("CY_STEM_FUSE") != "0":
             with pytest.raises(Exception, match="not materialised"):
+                det.read_conv(name, ref.numel())
+            continue
+        if name == "model.2.m.2.cv1" and prec == "fp16" and env.get("CY_BNECK_FUSE") == "1":
+            with pytest.raises(Exception, match="ran fused"):
                 det.read_conv(name, ref.numel())
             continue
         got = torch.from_numpy(det.read_conv(name, ref.numel()))

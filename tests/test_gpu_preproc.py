@@ -174,3 +174,42 @@ def test_chid_stage_selection_matches_reference_golden(pname, iname):
         np.testing.assert_allclose(got[..., :3], ref, rtol=3e-7, atol=1e-30)       # un-normalised pipelines: values ~1e-7, so relative
     else:
         np.testing.assert_allclose(got[..., :3], ref, rtol=5e-7, atol=5e-7 * scale * float(np.abs(ref).max()))
+
+
+GOLDEN_PIPES = {   # pipelines whose outputs the imported reference wrote into tests/golden/preproc.npz (oracle/gen_golden.py:PIPELINES)
+    "bkg": lambda M: [M.BkgSubtractor(sigma=3)],
+    "bkg_box": lambda M: [M.BkgSubtractor(sigma=3, use_mask_box=True, mask_fract=0.7)],
+    "shift": lambda M: [M.SigmaClipShifter(sigma=1)],
+    "clip": lambda M: [M.SigmaClipper(sigma_low=10, sigma_up=10)],
+    "clip_1_3": lambda M: [M.SigmaClipper(sigma_low=1, sigma_up=3)],
+    "zscale": lambda M: [M.ZScaleTransformer(contrasts=[0.25] * 3)],
+    "zscale_c40": lambda M: [M.ZScaleTransformer(contrasts=[0.4] * 3)],
+    "minmax": lambda M: [M.MinMaxNormalizer(norm_min=0, norm_max=255)],
+    "zscale_minmax": PIPES["zscale_minmax"], "chan3_minmax": PIPES["chan3_minmax"], "full": PIPES["full"],
+    "chan3_1_20": lambda M: [M.ChanResizer(nchans=3), M.Chan3Trasformer(sigma_clip_baseline=0, sigma_clip_low=1, sigma_clip_up=20,
+                                                                        zscale_contrast=0.25)],
+}
+
+
+@pytest.mark.parametrize("pname", sorted(GOLDEN_PIPES))
+@pytest.mark.parametrize("iname", ["galaxy", "syn192", "rag", "dense"])
+def test_preprocessed_image_matches_reference_golden_fp64(pname, iname):
+    """cy_preproc_planes: the device's preprocessed image in float64 against the REFERENCE's own output for the same stage list
+    (tests/golden/preproc.npz, written by the imported caesar_yolo.preprocessing): identical zero mask, values to 1e-10
+    relative (statistics are reductions in a different order; every per-pixel map is replayed operation for operation)."""
+    det = detector("fp32", max_imgsz=640)
+    g = np.load(os.path.join(ROOT, "tests/golden/preproc.npz"))
+    img = g["in/" + iname]
+    th, tw = img.shape
+    mosaic, xy = _mosaic(det, [img])
+    cfg = PP.DataPreprocessor(GOLDEN_PIPES[pname](PP)).program()
+    planes, status = det.preproc_planes(mosaic, xy, th, tw, cfg)
+    torch.cuda.synchronize()
+    assert status.cpu().tolist() == [0]
+    got = planes[0].cpu().numpy().transpose(1, 2, 0)               # (H, W, 3)
+    ref = g["out/%s/%s" % (iname, pname)]
+    if ref.ndim == 2:
+        assert np.array_equal(got[:, :, 0], got[:, :, 1]) and np.array_equal(got[:, :, 0], got[:, :, 2])
+        got = got[:, :, 0]
+    assert np.array_equal(got == 0, ref == 0)
+    np.testing.assert_allclose(got, ref, rtol=1e-10, atol=1e-13)
