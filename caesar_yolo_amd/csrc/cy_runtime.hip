@@ -38,14 +38,15 @@ struct cy_ctx {
         float* cand = nullptr; int* cand_anchor = nullptr; int* cand_count = nullptr; uint64_t* keys = nullptr;
         float* det = nullptr; int* det_anchor = nullptr; int* det_count = nullptr; int* merge_err = nullptr; int* out_src = nullptr;
         double* pre_params = nullptr; double* pre_histeq = nullptr; double* pre_scratch = nullptr;
-    } sb[2];
+    } sb[3];                                            // [0], [1]: alternating sets of the batch pipeline; [2]: small batches (side forward stream)
     int slot = 0;                                       // buffer set used by the stage entry points
     StageBufs& S() { return sb[slot]; }
     size_t pre_scratch_elems = 0;
     int cap = 0, cap_pow2 = 0;
     hipStream_t s_pre = nullptr, s_post = nullptr;      // side streams of the pipelined cy_detect_tiles
-    hipEvent_t ev_call = nullptr, ev_pre[2] = {nullptr, nullptr}, ev_fwd[2] = {nullptr, nullptr}, ev_post[2] = {nullptr, nullptr};
-    unsigned long batches = 0;                          // cy_detect_tiles calls since load / flush
+    hipEvent_t ev_call = nullptr, ev_pre[3] = {nullptr, nullptr, nullptr}, ev_fwd[3] = {nullptr, nullptr, nullptr}, ev_post[3] = {nullptr, nullptr, nullptr};
+    unsigned long batches = 0;                          // cy_detect_tiles calls on the main pipeline since load / flush
+    unsigned long small_batches = 0;                    // ... and on the small-batch lane (buffer set 2, forward on s_fwd2)
     bool mosaic_dirty = true;                           // cy_mosaic_prepare ran on the caller's stream since the last cy_detect_tiles
     int* counters = nullptr;                            // device: [0] degenerate boxes dropped by the IoU merge, [1] tiles whose candidates overflowed `cap`
     // optional per-launch timing of the forward ops (hipEvents on the caller's stream)
@@ -99,9 +100,9 @@ void free_all(cy_ctx* c) {
     if (c->counters) { hipFree(c->counters); c->counters = nullptr; }
     if (c->s_pre) { hipStreamDestroy(c->s_pre); c->s_pre = nullptr; }
     if (c->s_post) { hipStreamDestroy(c->s_post); c->s_post = nullptr; }
-    hipEvent_t* evs[] = {&c->ev_call, &c->ev_pre[0], &c->ev_pre[1], &c->ev_fwd[0], &c->ev_fwd[1], &c->ev_post[0], &c->ev_post[1]};
+    hipEvent_t* evs[] = {&c->ev_call, &c->ev_pre[0], &c->ev_pre[1], &c->ev_pre[2], &c->ev_fwd[0], &c->ev_fwd[1], &c->ev_fwd[2], &c->ev_post[0], &c->ev_post[1], &c->ev_post[2]};
     for (hipEvent_t* e : evs) if (*e) { hipEventDestroy(*e); *e = nullptr; }
-    c->batches = 0;
+    c->batches = 0; c->small_batches = 0;
 }
 
 struct Reader {
@@ -368,7 +369,7 @@ int upload_weights(cy_ctx* c, const void* buf, size_t nbytes) {
     const bool low = !(getenv("CY_SIDE_PRIO") && atoi(getenv("CY_SIDE_PRIO")) == 0);
     HIPCHK(c, hipStreamCreateWithPriority(&c->s_pre, hipStreamNonBlocking, low ? prio_lo : 0));
     HIPCHK(c, hipStreamCreateWithPriority(&c->s_post, hipStreamNonBlocking, low ? prio_lo : 0));
-    hipEvent_t* evs[] = {&c->ev_call, &c->ev_pre[0], &c->ev_pre[1], &c->ev_fwd[0], &c->ev_fwd[1], &c->ev_post[0], &c->ev_post[1]};
+    hipEvent_t* evs[] = {&c->ev_call, &c->ev_pre[0], &c->ev_pre[1], &c->ev_pre[2], &c->ev_fwd[0], &c->ev_fwd[1], &c->ev_fwd[2], &c->ev_post[0], &c->ev_post[1], &c->ev_post[2]};
     for (hipEvent_t* e : evs) HIPCHK(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
     c->loaded = true;
     return CY_OK;
@@ -997,7 +998,7 @@ int cy_iou_merge(cy_ctx* c, const float* d_det, const int* d_count, int B, float
 int cy_detect_tiles(cy_ctx* c, const float* d_mosaic, int MH, int MW, const int* h_tiles, int B, int th, int tw, int imgsz,
                     const cy_preproc_cfg* cfg, float conf, float iou, double soft, double hard,
                     float* d_out, int* d_out_count, int* d_status, void* stream) {
-    // Software pipeline over consecutive calls (batches): three streams, two buffer sets.
+    // Software pipeline over consecutive calls (batches): three streams, two buffer sets (+ the small-batch lane below).
     //   s_pre  : preprocessing of batch i      (waits: forward of batch i-2 has consumed this set's network input)
     //   stream : forward of batch i            (waits: preprocessing i; post-processing i-2 has consumed this set's head output)
     //   s_post : decode/NMS/IoU-merge of batch i (waits: forward i)
@@ -1007,14 +1008,23 @@ int cy_detect_tiles(cy_ctx* c, const float* d_mosaic, int MH, int MW, const int*
     cy_letterbox lb;
     if (cy_letterbox_geometry(th, tw, imgsz, &lb)) return fail(c, CY_ERR_ARG, "bad tile/imgsz");
     hipStream_t sm = (hipStream_t)stream;
-    const int sl = (int)(c->batches & 1);
-    const bool reuse = c->batches >= 2;
-    c->slot = sl;
+    // Small batches (the ragged edge classes of a grid: 39 + 39 + 1 of the 1600 tiles of the 16k mosaic) take their own lane:
+    // buffer set 2, forward on the second stream / workspace.  A batch of 1-39 tiles is a chain of ~105 kernels of a few
+    // workgroups each -- 4.2 ms for ONE tile, 6.2 ms for 39, i.e. 8 % of a pass for 4 % of its pixels when run in line -- but
+    // hardly any work: beside the full batches of the main lane it costs about its share of the chip.  The caller
+    // interleaves them with the full batches (TileEngine).  CY_SMALL_LANE=0 keeps every batch on the main lane.
+    static const int small_lane = env_knob("CY_SMALL_LANE", 1);
+    const bool small = small_lane && c->prec == PREC_F16 && B < 64 && c->cfg.max_batch >= 64;    // (contexts sized for tile batches only)
     int rc = CY_OK;
+    if (small) { rc = ensure_second_workspace(c); if (rc) return rc; }
+    const int sl = small ? 2 : (int)(c->batches & 1);
+    const bool reuse = small ? c->small_batches >= 1 : c->batches >= 2;
+    hipStream_t sf = small ? c->s_fwd2 : sm;
+    c->slot = sl;
     // order the side streams after whatever the caller already queued on `stream` -- only where that matters: the first batch
     // after load / flush, or after cy_mosaic_prepare.  Later batches are ordered by ev_fwd / ev_post alone, so that the
     // preprocessing of batch i does not wait for the forward of batch i-1 that is already queued on `stream`.
-    if (c->batches == 0 || c->mosaic_dirty) {
+    if (c->batches + c->small_batches == 0 || c->mosaic_dirty) {
         HIPCHK(c, hipEventRecord(c->ev_call, sm));
         HIPCHK(c, hipStreamWaitEvent(c->s_pre, c->ev_call, 0));
         c->mosaic_dirty = false;
@@ -1023,19 +1033,22 @@ int cy_detect_tiles(cy_ctx* c, const float* d_mosaic, int MH, int MW, const int*
     rc = cy_preproc(c, d_mosaic, MH, MW, h_tiles, B, th, tw, imgsz, cfg, c->S().netin, d_status, c->s_pre);
     if (rc) { c->slot = 0; return rc; }
     HIPCHK(c, hipEventRecord(c->ev_pre[sl], c->s_pre));
-    // (tried: the forward of batches below 64 tiles on the second stream, beside the neighbouring batches: +0.4 % at N = 1,
-    // within the noise, and it blurs the per-launch event timing -> not kept)
-    HIPCHK(c, hipStreamWaitEvent(sm, c->ev_pre[sl], 0));
-    if (reuse) HIPCHK(c, hipStreamWaitEvent(sm, c->ev_post[sl], 0));
-    rc = forward_split(c, c->S().netin, B, lb.H, lb.W, c->S().pred, sm);
+    HIPCHK(c, hipStreamWaitEvent(sf, c->ev_pre[sl], 0));
+    if (reuse) HIPCHK(c, hipStreamWaitEvent(sf, c->ev_post[sl], 0));
+    if (small) {
+        c->split_last = false;
+        rc = forward_on(c, c->S().netin, B, lb.H, lb.W, c->S().pred, sf, c->ws2, c->ws2_bytes, false);
+    } else {
+        rc = forward_split(c, c->S().netin, B, lb.H, lb.W, c->S().pred, sm);
+    }
     if (rc) { c->slot = 0; return rc; }
-    HIPCHK(c, hipEventRecord(c->ev_fwd[sl], sm));
+    HIPCHK(c, hipEventRecord(c->ev_fwd[sl], sf));
     HIPCHK(c, hipStreamWaitEvent(c->s_post, c->ev_fwd[sl], 0));
     rc = cy_decode_nms(c, c->S().pred, B, lb.H, lb.W, th, tw, conf, iou, c->S().det, c->S().det_anchor, c->S().det_count, c->s_post);
     if (!rc) rc = cy_iou_merge(c, c->S().det, c->S().det_count, B, conf, soft, hard, d_out, d_out_count, nullptr, c->s_post);
     if (rc) { c->slot = 0; return rc; }
     HIPCHK(c, hipEventRecord(c->ev_post[sl], c->s_post));
-    c->batches++;
+    if (small) c->small_batches++; else c->batches++;
     c->slot = 0;
     return CY_OK;
 }
@@ -1049,7 +1062,11 @@ int cy_detect_flush(cy_ctx* c, void* stream) {
         HIPCHK(c, hipStreamWaitEvent(sm, c->ev_post[sl], 0));
         HIPCHK(c, hipStreamWaitEvent(sm, c->ev_pre[sl], 0));
     }
-    c->batches = 0;                  // the next call starts a new pipeline: it orders the side streams behind `stream` again
+    if (c->small_batches) {          // the small-batch lane (one buffer set: its batches are ordered among themselves)
+        HIPCHK(c, hipStreamWaitEvent(sm, c->ev_post[2], 0));
+        HIPCHK(c, hipStreamWaitEvent(sm, c->ev_pre[2], 0));
+    }
+    c->batches = 0; c->small_batches = 0;     // the next call starts a new pipeline: it orders the side streams behind `stream` again
     return CY_OK;
 }
 

@@ -175,6 +175,19 @@ class TileEngine(object):
                 xy = [(self.grid[t][0] - ox, self.grid[t][2] - oy) for t in chunk]
                 self.plan.append((th, tw, len(chunk), xy, row, img))
                 row += len(chunk)
+        # Launch order: the small batches (ragged edge classes, < 64 tiles) are slotted between the full ones -- the library runs
+        # their forward on a second stream (cy_detect_tiles, "small-batch lane"), where a chain of ~105 tiny kernels costs its
+        # share of the chip instead of its latency (4-6 ms each in line on the 16k mosaic).  Output rows stay where they were.
+        big = [p for p in self.plan if p[2] >= 64]
+        small = [p for p in self.plan if p[2] < 64]
+        if big and small:
+            order = []
+            for i, p in enumerate(big):
+                order.append(p)
+                if i < len(small):
+                    order.append(small[i])
+            order += small[len(big):]
+            self.plan = order
         dev = detector.tdev
         # fixed-capacity record buffer: [tile][300*6 floats | count | status | tile id]; one extra row at the end carries this
         # rank's event counters (degenerate boxes dropped, tiles whose candidates overflowed), so ONE collective moves all
