@@ -51,6 +51,31 @@ __device__ __forceinline__ float silu_exact(float x) { return x / (1.0f + expf(-
 __device__ __forceinline__ float silu_fast(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896341f));
 }
+// The epilogue of the fp16 kernels for the 16 values a lane holds of one pixel (four accumulators of four channels): bias +
+// SiLU with two values per VALU instruction where the ISA has a packed fp32 form (add, mul; exp2 and rcp stay scalar), and
+// the activation switch as ONE uniform branch (written per value it becomes a v_cndmask per value behind an unconditional SiLU).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void bias_act16(const f32x4& a0, const f32x4& a1, const f32x4& a2, const f32x4& a3, const float (&bv)[16],
+                                           bool act, float (&v)[16]) {
+    const f32x4 acc[4] = {a0, a1, a2, a3};
+    if (act) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x2 t = f32x2{acc[ni][2 * h], acc[ni][2 * h + 1]} + f32x2{bv[ni * 4 + 2 * h], bv[ni * 4 + 2 * h + 1]};
+                f32x2 e = t * f32x2{-1.44269504088896341f, -1.44269504088896341f};
+                e = f32x2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])} + f32x2{1.0f, 1.0f};
+                t = t * f32x2{__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+                v[ni * 4 + 2 * h] = t[0]; v[ni * 4 + 2 * h + 1] = t[1];
+            }
+    } else {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[ni * 4 + j] = acc[ni][j] + bv[ni * 4 + j];
+    }
+}
 
 template <typename T> struct Elem;
 template <> struct Elem<f16> { static constexpr int BKE = 64, EPC = 8, ES = 2; };
@@ -501,14 +526,7 @@ __global__ __launch_bounds__(WM * 128) void conv3x3_halo_kernel(const ConvArgs a
         if (y >= H || x >= W) continue;
         const long pix = ((long)b * H + y) * W + x;
         float v[16];
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float t = acc[ni][mi][j] + bv[ni * 4 + j];
-                if (a.act) t = silu_fast(t);
-                v[ni * 4 + j] = t;
-            }
+        bias_act16(acc[0][mi], acc[1][mi], acc[2][mi], acc[3][mi], bv, a.act != 0, v);
         if (cbase + 16 <= a.Cout) {
             f16* dst = reinterpret_cast<f16*>(a.out) + pix * a.out_ct + a.out_coff + cbase;
             if (a.res) {
@@ -752,165 +770,232 @@ static hipError_t launch_pp(const ConvArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------ 3x3 s1, Cin = 64: persistent
 // The six bottleneck convolutions of the full-resolution C2f (64 -> 64 channels over 1M pixels per 64-tile batch) have
 // only nine K-slabs per output patch, so a one-patch-per-workgroup kernel spends most of its time in prologue/epilogue
-// (measured: 16 rounds x ~10 us).  Here a workgroup is persistent: the whole 64 x (9 x 64) weight panel is staged in LDS
-// ONCE (72 KB), next to a double-buffered input halo (2 x 42 KB), and the nine taps of a patch run without any barrier; the halo of the next patch streams in (LDS-DMA) under the current patch's MFMAs and
-// stores.  One barrier per patch.
+// (measured: 16 rounds x ~10 us).  Here a workgroup is persistent (one per CU): the whole 64 x (9 x 64) weight panel is
+// staged in LDS ONCE (72 KB) next to two input-halo buffers (2 x 42 KB), and the nine taps of a patch run without a barrier.
 // KC = input channels (64, or 32 with 64-byte LDS rows and the 64-byte-chunk weight copy: the 32-channel bottlenecks of the
 // n/s scales and of YOLO11's C3k blocks; the output side still walks all 64 packed rows, half of them zero for Cout = 32).
-template <int KC>
-__global__ __launch_bounds__(256) void conv3x3_c64_kernel(const ConvArgs a) {
-    constexpr int TH = 16, TW = 16, NW = 4, NI = 4;      // 4 waves, one per SIMD, each 64 px x 64 ch with the full register file
-    constexpr int RB = KC * 2, RPP = 1024 / RB, NCH = KC / 8, KK = KC / 32;     // row bytes, rows per 1 KiB DMA piece, 16-byte chunks per row
-    constexpr int PR = (TH + 2) * (TW + 2), NWI = (PR + RPP - 1) / RPP, PROUNDS = (NWI + NW - 1) / NW;
+//
+// Two wave groups.  Round 1's form had four waves (one per SIMD) and a double-buffered halo; its in-kernel stamps showed, per
+// patch and wave, 6.2k cycles of fragment reads + MFMAs, 5.2k of epilogue (bias, SiLU, residual, stores), 1.9k of LDS-DMA issue
+// and next to no waiting -- with ONE wave per SIMD all of it is serial.  Now a workgroup has 8 waves = two groups of four
+// (waves w and w + 4 share a SIMD); its patches alternate between the groups, and in every phase one group runs the MFMAs of
+// its patch while the other runs the "back" of its previous one: request the halo of its next patch into its own (single)
+// halo buffer, epilogue, wait.  One workgroup barrier per phase orders both hand-overs (halo landed -> readable; halo read ->
+// writable).  256 tiles of 128x128x64: 0.43-0.48 -> 0.35-0.39 ms per conv (3.5 TB/s of HBM traffic without, 4.5 TB/s with a
+// residual input: the kernel is now bound by memory, not by issue; making the halo requests and the epilogue cheaper -- uniform
+// address parts in soffset, an interior-patch path without border tests, packed fp32 math -- no longer moved it).
+template <int KC, bool ACT, bool RES>
+__global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvArgs a) {
+    constexpr int TH = 16, TW = 16, NG = 4, NI = 4;      // NG waves per group, each 64 px x 64 ch
+    constexpr int RB = KC * 2, RPP = 1024 / RB, NCH = KC / 8, KK = KC / 32;
+    constexpr int PR = (TH + 2) * (TW + 2), NWI = (PR + RPP - 1) / RPP, PROUNDS = (NWI + NG - 1) / NG;
     auto swz = [](int chunk, int row) { return KC == 64 ? (chunk ^ (row & 7)) : (chunk ^ (((row >> 2) & 1) << 1)); };
     constexpr int P_BYTES = (NWI + 1) * 1024;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) void lds_void;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave;
+    const int grp = wave >> 2, wm = wave & 3;
     const int fr = lane & 15, fq = lane >> 4;
     const int H = a.Hi, W = a.Wi;
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     const int npatch = a.B * tiles_y * tiles_x;
-    const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in0), 0, a.in0_bytes, 0x00020000);
+    // halo requests: offset = (per-lane part, fixed for the whole launch, in voffset) + (per-patch part, uniform, in soffset).
+    // soffset is unsigned and the per-patch part starts one row + one pixel before the patch, so the resource base is moved
+    // back by that much (num_records widened to match); only voffset is range-checked: lanes outside the image get CY_OOB.
+    const unsigned bias_bytes = (unsigned)((W + 1) * a.in0_ct) * 2u;
+    const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.in0)) - bias_bytes, 0,
+                                                       a.in0_bytes + 2 * bias_bytes, 0x00020000);
 
-    // ---- weights -> LDS once: [tap][64 rows][128 B], same source-side swizzle as every other tile image
-    constexpr int W_BYTES = 9 * 64 * RB, WPIECES = W_BYTES / 1024, PPT = 64 / RPP;      // pieces per tap
+    constexpr int W_BYTES = 9 * 64 * RB, WPIECES = W_BYTES / 1024, PPT = 64 / RPP;
     char* const Wl = smem;
-    char* const Pl = smem + W_BYTES;
+    char* const P = smem + W_BYTES + grp * P_BYTES;           // this group's halo buffer
     {
         const auto rsw = KC == 64 ? __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wgt), 0, a.wgt_bytes, 0x00020000)
                                   : __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wgt32), 0, a.wgt32_bytes, 0x00020000);
 #pragma unroll
-        for (int j = 0; j < WPIECES / NW; ++j) {
-            const int pc = j * NW + wave;                   // pieces of RPP rows: piece = tap*PPT + row block
+        for (int j = 0; j < (WPIECES + 7) / 8; ++j) {
+            const int pc = j * 8 + wave;
+            if (pc >= WPIECES) break;                       // (36 pieces for KC = 32)
             const int tap = pc / PPT, row = (pc % PPT) * RPP + lane / NCH;
             const int q = swz(lane % NCH, row);
-            const unsigned off = (unsigned)((tap * 128 + row) * RB + q * 16);         // slab-major packing, rows padded to 128, one K chunk
+            const unsigned off = (unsigned)((tap * 128 + row) * RB + q * 16);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)(Wl + pc * 1024), 16, off, 0, 0, 0);
         }
     }
-    const int cbase = fq * 16;                             // 16 contiguous channels per lane
-    float bv[16];
+    const int cbase = fq * 16;
+    f32x2 bv[8];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) bv[j] = a.bias[cbase + j];
+    for (int j = 0; j < 8; ++j) bv[j] = f32x2{a.bias[cbase + 2 * j], a.bias[cbase + 2 * j + 1]};
 
-    auto dma_patch = [&](int buf, int pidx) {
+    // per-lane parts of the PROUNDS halo pieces this wave requests: byte offset relative to the halo's first pixel, and the
+    // halo row / column (packed) for the border test
+    unsigned rel[PROUNDS];
+#pragma unroll
+    for (int j = 0; j < PROUNDS; ++j) {
+        const int wi = j * NG + wm;
+        const int r = wi * RPP + lane / NCH;
+        const int ry = r / (TW + 2), rx = r - ry * (TW + 2);
+        const int q = swz(lane % NCH, r);
+        rel[j] = r < PR ? (unsigned)(((ry * W + rx) * a.in0_ct + q * 8) * 2) : CY_OOB;
+    }
+    const int rlane = lane / NCH;
+    auto dma_patch = [&](int pidx) {                       // by the four waves of the group that owns the patch
         const int tx = pidx % tiles_x, ty = (pidx / tiles_x) % tiles_y, b = pidx / (tiles_x * tiles_y);
         const int y0 = ty * TH, x0 = tx * TW;
+        const unsigned so = bias_bytes + (unsigned)((((b * H + y0 - 1) * W + x0 - 1) * a.in0_ct + a.in0_coff) * 2);
+        const bool interior = y0 >= 1 && x0 >= 1 && y0 + TH + 1 <= H && x0 + TW + 1 <= W;
+        if (interior) {
 #pragma unroll
-        for (int j = 0; j < PROUNDS; ++j) {
-            const int wi = j * NW + wave;
-            const int r = wi * RPP + lane / NCH;
-            const int ry = r / (TW + 2), rx = r - ry * (TW + 2);
-            const int y = y0 + ry - 1, x = x0 + rx - 1;
-            const int q = swz(lane % NCH, r);
-            const bool ok = r < PR && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-            const unsigned off = ok ? (unsigned)(((b * H + y) * W + x) * a.in0_ct + a.in0_coff + q * 8) * 2u : CY_OOB;
-            char* dst = Pl + buf * P_BYTES + (wi < NWI ? wi : NWI) * 1024;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_void*)dst, 16, off, 0, 0, 0);
+            for (int j = 0; j < PROUNDS; ++j) {
+                const int wi = j * NG + wm;
+                dma_piece(rs0, (lds_ptr_t*)(P + (wi < NWI ? wi : NWI) * 1024), rel[j], so);
+            }
+        } else {
+            // halo rows [ylo, yhi) and columns [xlo, xhi) are inside the image
+            const int ylo = y0 >= 1 ? 0 : 1, yhi = H - y0 + 1, xlo = x0 >= 1 ? 0 : 1, xhi = W - x0 + 1;
+#pragma unroll
+            for (int j = 0; j < PROUNDS; ++j) {
+                const int wi = j * NG + wm;
+                const int r = wi * RPP + rlane, ry = (r * 3641) >> 16, rx = r - ry * (TW + 2);      // r / 18 for r < 400
+                const bool ok = ry >= ylo && ry < yhi && rx >= xlo && rx < xhi;
+                dma_piece(rs0, (lds_ptr_t*)(P + (wi < NWI ? wi : NWI) * 1024), ok ? rel[j] : CY_OOB, so);
+            }
         }
     };
 
-    int pidx = blockIdx.x;
-    if (pidx < npatch) dma_patch(0, pidx);
-    CY_WAIT_VM(0);
+    // patch n of this workgroup = blockIdx.x + n * gridDim.x, owned by group n & 1; NP of them
+    const int NP = (int)blockIdx.x < npatch ? (npatch - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    if (grp < NP) dma_patch(blockIdx.x + grp * gridDim.x);
+    // (the builtin, not inline asm: the compiler then knows that the bias loads above have landed; with the asm form it
+    // put an `s_waitcnt vmcnt(0)` in front of the first use of bv[] INSIDE the loop, i.e. between the halo requests of a
+    // back phase and its epilogue, which exposed the whole DMA latency there)
+    __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
     __builtin_amdgcn_s_barrier();
-    int it = 0;
-    for (; pidx < npatch; pidx += gridDim.x, ++it) {
-        const int nxt = pidx + gridDim.x;
-        if (nxt < npatch) dma_patch((it + 1) & 1, nxt);
-        const char* P = Pl + (it & 1) * P_BYTES;
-        f32x4 acc[NI][4];
+
+    // fragment addresses as (one of a few lane-dependent bases) + (a compile-time offset): the swizzle of halo row R0 + c depends
+    // on (R0 + c) & 7 only, and the second K half (chunk + 4) is the swizzle of row + 4, so eight bases cover all 72 fragments
+    // of a patch (computed one by one they are 36 live registers, which at two waves per SIMD spill)
+    const int R0 = wm * 4 * (TW + 2) + fr;
+    unsigned xb[8], wb0[KK];
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
+    for (int k8 = 0; k8 < 8; ++k8) xb[k8] = (unsigned)(R0 * RB + (swz(fq, (R0 + k8) & 7) << 4));
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // 9*KK groups (tap, kk) of 8 fragment reads + 16 MFMAs.  With ONE wave per SIMD nothing else hides the LDS latency,
-        // so the fragments are double-buffered in registers: group g+1 is read before the MFMAs of group g are issued
-        // (fences keep that order; the workgroup has 512 VGPRs per lane to spend).
-        f16x8 xa[2][4], wb[2][NI];
-        auto load_group = [&](int g, f16x8* x, f16x8* w) {
-            const int tap = g / KK, kk = g % KK, kh = tap / 3, kw = tap - kh * 3, qf = fq + 4 * kk;
+    for (int kk = 0; kk < KK; ++kk) wb0[kk] = (unsigned)(fr * RB + (swz(fq + 4 * kk, fr) << 4));
+    f32x4 acc[NI][4];
+    const bool vec_out = cbase + 16 <= a.Cout;
+    const int out_lane = fr * a.out_ct + cbase, res_lane = fr * a.res_ct + cbase;       // element offsets of the lane inside a patch row
+    // phase ph: group ph & 1 runs the MFMAs of patch ph; the other group the back of patch ph - 1 (+ the halo of patch ph + 1)
+    for (int ph = 0; ph <= NP; ++ph) {
+        if ((ph & 1) == grp) {
+            if (ph < NP) {
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                const int r = (wm * 4 + mi + kh) * (TW + 2) + kw + fr;
-                x[mi] = *reinterpret_cast<const f16x8*>(P + r * RB + (swz(qf, r) << 4));
-            }
+                for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-                w[ni] = *reinterpret_cast<const f16x8*>(Wl + (tap * 64 + ni * 16 + fr) * RB + (swz(qf, fr) << 4));
-        };
-        // residual of this patch: requested now, used in the epilogue (its latency hides under the 288 MFMAs)
-        const int tx = pidx % tiles_x, ty = (pidx / tiles_x) % tiles_y, b = pidx / (tiles_x * tiles_y);
-        f16x8 rres[4][2];
-        if (a.res && cbase + 16 <= a.Cout) {
+                    for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+                f16x8 xa[2][4], wb[2][NI];
+                auto load_group = [&](int g, f16x8* x, f16x8* w) {
+                    const int tap = g / KK, kk = g % KK, kh = tap / 3, kw = tap - kh * 3;
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                const int y = ty * TH + wm * 4 + mi, x = tx * TW + fr;
-                const bool ok = y < H && x < W;
-                const long pix = ok ? ((long)b * H + y) * W + x : 0;      // masked lanes read pixel 0 (valid memory), never used
-                const f16* rp = reinterpret_cast<const f16*>(a.res) + pix * a.res_ct + a.res_coff + cbase;
-                rres[mi][0] = *reinterpret_cast<const f16x8*>(rp);
-                rres[mi][1] = *reinterpret_cast<const f16x8*>(rp + 8);
-            }
-        }
-        load_group(0, xa[0], wb[0]);
+                    for (int mi = 0; mi < 4; ++mi) {
+                        const int c = (mi + kh) * (TW + 2) + kw;                     // halo row = R0 + c
+                        x[mi] = *reinterpret_cast<const f16x8*>(P + xb[(c + 4 * kk) & 7] + c * RB);
+                    }
 #pragma unroll
-        for (int g = 0; g < 9 * KK; ++g) {
-            if (g + 1 < 9 * KK) load_group(g + 1, xa[(g + 1) & 1], wb[(g + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
+                    for (int ni = 0; ni < NI; ++ni)
+                        w[ni] = *reinterpret_cast<const f16x8*>(Wl + wb0[kk] + (tap * 64 + ni * 16) * RB);
+                };
+                load_group(0, xa[0], wb[0]);
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
+                for (int g = 0; g < 9 * KK; ++g) {
+                    if (g + 1 < 9 * KK) load_group(g + 1, xa[(g + 1) & 1], wb[(g + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[g & 1][ni], xa[g & 1][mi], acc[ni][mi], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // the next halo (requested before this patch's MFMAs) has landed by now; waiting for it HERE, before the stores of the
-        // epilogue are issued, keeps those stores out of the wait: they retire under the next patch's MFMAs
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        CY_WAIT_VM(0);
-        // ---- epilogue of this patch
+                    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int y = ty * TH + wm * 4 + mi, x = tx * TW + fr;
-            if (y >= H || x >= W) continue;
-            const long pix = ((long)b * H + y) * W + x;
-            float v[16];
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float t = acc[ni][mi][j] + bv[ni * 4 + j];
-                    if (a.act) t = silu_fast(t);
-                    v[ni * 4 + j] = t;
+                        for (int mi = 0; mi < 4; ++mi)
+                            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[g & 1][ni], xa[g & 1][mi], acc[ni][mi], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-            if (cbase + 16 <= a.Cout) {
-                f16* dst = reinterpret_cast<f16*>(a.out) + pix * a.out_ct + a.out_coff + cbase;
-                if (a.res) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this group is done reading its halo
+            }
+        } else if (ph >= 1) {
+            f16x8 rres[4][2];
+            const int pidx = blockIdx.x + (ph - 1) * gridDim.x;
+            const int tx = pidx % tiles_x, ty = (pidx / tiles_x) % tiles_y, b = pidx / (tiles_x * tiles_y);
+            const int yw = ty * TH + wm * 4, x = tx * TW + fr;                 // first of the wave's four rows; the lane's column
+            const long rowpix = ((long)b * H + yw) * W + tx * TW;              // uniform: first pixel of the wave's first row
+            const bool xok = x < W;
+            if (RES) {                                     // residual of the patch: its latency hides under the DMA issue and the SiLUs below
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) { v[j] += (float)rres[mi][0][j]; v[8 + j] += (float)rres[mi][1][j]; }
+                for (int mi = 0; mi < 4; ++mi) {
+                    const bool ok = yw + mi < H && xok && vec_out;
+                    // (masked lanes read the start of the patch's first pixel: valid memory, never used)
+                    const f16* rp = reinterpret_cast<const f16*>(a.res) + ((rowpix + (yw + mi < H ? (long)mi * W : 0)) * a.res_ct + a.res_coff) + (ok ? res_lane : 0);
+                    rres[mi][0] = *reinterpret_cast<const f16x8*>(rp);
+                    rres[mi][1] = *reinterpret_cast<const f16x8*>(rp + 8);
                 }
-                f16x8 o0, o1;
+            }
+            if (ph + 1 < NP) dma_patch(blockIdx.x + (ph + 1) * gridDim.x);
+            // bias + SiLU in place, two values per instruction where the ISA has a packed form
+            if (ACT) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { o0[j] = (f16)v[j]; o1[j] = (f16)v[8 + j]; }
-                *reinterpret_cast<f16x8*>(dst) = o0;
-                *reinterpret_cast<f16x8*>(dst + 8) = o1;
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            f32x2 t = f32x2{acc[ni][mi][2 * h], acc[ni][mi][2 * h + 1]} + bv[ni * 2 + h];
+                            f32x2 e = t * f32x2{-1.44269504088896341f, -1.44269504088896341f};
+                            e = f32x2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])} + f32x2{1.0f, 1.0f};
+                            t = t * f32x2{__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+                            acc[ni][mi][2 * h] = t[0]; acc[ni][mi][2 * h + 1] = t[1];
+                        }
             } else {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const int c = cbase + j;
-                    if (c >= a.Cout) continue;
-                    float t = v[j];
-                    if (a.res) t += (float)(reinterpret_cast<const f16*>(a.res)[pix * a.res_ct + a.res_coff + c]);
-                    reinterpret_cast<f16*>(a.out)[pix * a.out_ct + a.out_coff + c] = (f16)t;
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[ni][mi][j] += bv[ni * 2 + (j >> 1)][j & 1];
+            }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                if (yw + mi >= H) break;                   // (uniform)
+                if (!xok) continue;
+                if (vec_out) {
+                    f16* dst = reinterpret_cast<f16*>(a.out) + ((rowpix + (long)mi * W) * a.out_ct + a.out_coff) + out_lane;
+                    float v[16];
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[ni * 4 + j] = acc[ni][mi][j];
+                    if (RES) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { v[j] += (float)rres[mi][0][j]; v[8 + j] += (float)rres[mi][1][j]; }
+                    }
+                    f16x8 o0, o1;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { o0[j] = (f16)v[j]; o1[j] = (f16)v[8 + j]; }
+                    *reinterpret_cast<f16x8*>(dst) = o0;
+                    *reinterpret_cast<f16x8*>(dst + 8) = o1;
+                } else {
+                    const long pix = rowpix + (long)mi * W + fr;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const int c = cbase + j;
+                        if (c >= a.Cout) continue;
+                        float t = acc[j >> 2][mi][j & 3];
+                        if (RES) t += (float)(reinterpret_cast<const f16*>(a.res)[pix * a.res_ct + a.res_coff + c]);
+                        reinterpret_cast<f16*>(a.out)[pix * a.out_ct + a.out_coff + c] = (f16)t;
+                    }
                 }
             }
+            CY_WAIT_VM(0);                                 // the halo requested above has landed (and the stores are out)
         }
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();                        // every wave is done reading this patch's halo; the landed one is published
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -920,12 +1005,18 @@ static hipError_t launch_c64(const ConvArgs& a, hipStream_t s) {
     const size_t lds = 9 * 64 * KC * 2 + 2 * (NWI + 1) * 1024;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_kernel<KC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_kernel<KC, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_kernel<KC, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_kernel<KC, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_kernel<KC, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const int npatch = a.B * ((a.Hi + 15) / 16) * ((a.Wi + 15) / 16);
     const int grid = npatch < 256 ? npatch : 256;                                  // one persistent workgroup per CU
-    hipLaunchKernelGGL(conv3x3_c64_kernel<KC>, dim3(grid), dim3(256), lds, s, a);
+    if (a.act && a.res) hipLaunchKernelGGL((conv3x3_c64_kernel<KC, true, true>), dim3(grid), dim3(512), lds, s, a);
+    else if (a.act) hipLaunchKernelGGL((conv3x3_c64_kernel<KC, true, false>), dim3(grid), dim3(512), lds, s, a);
+    else if (a.res) hipLaunchKernelGGL((conv3x3_c64_kernel<KC, false, true>), dim3(grid), dim3(512), lds, s, a);
+    else hipLaunchKernelGGL((conv3x3_c64_kernel<KC, false, false>), dim3(grid), dim3(512), lds, s, a);
     return hipGetLastError();
 }
 
@@ -1083,14 +1174,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo2_kernel(const ConvArgs a) {
         if (y >= H || x >= W) continue;
         const long pix = ((long)b * H + y) * W + x;
         float v[16];
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float t = acc[ni][mi][j] + bv[ni * 4 + j];
-                if (a.act) t = silu_fast(t);
-                v[ni * 4 + j] = t;
-            }
+        bias_act16(acc[0][mi], acc[1][mi], acc[2][mi], acc[3][mi], bv, a.act != 0, v);
         if (cbase + 16 <= a.Cout) {
             f16* dst = reinterpret_cast<f16*>(a.out) + pix * a.out_ct + a.out_coff + cbase;
             if (a.res) {
@@ -1374,14 +1458,7 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
         if (y >= H || x >= W || bb >= a.B) continue;
         const long pix = ((long)bb * H + y) * W + x;
         float v[16];
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float t = acc[ni][mi][j] + bv[ni * 4 + j];
-                if (a.act) t = silu_fast(t);
-                v[ni * 4 + j] = t;
-            }
+        bias_act16(acc[0][mi], acc[1][mi], acc[2][mi], acc[3][mi], bv, a.act != 0, v);
         if (cbase + 16 <= a.Cout) {
             f16* dst = reinterpret_cast<f16*>(a.out) + pix * a.out_ct + a.out_coff + cbase;
             if (res_vec) {
@@ -1599,14 +1676,7 @@ __global__ __launch_bounds__(512, (NB * MI <= 4 && RING == 2) ? 2 : 1) void conv
             const int b = m / HoWo, r = m - b * HoWo;
             const long opix = (long)b * a.out_bs + a.out_ro + r;
             float v[16];
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float t = acc[g * 4 + ni][mi][j] + bv[ni * 4 + j];
-                    if (a.act) t = silu_fast(t);
-                    v[ni * 4 + j] = t;
-                }
+            bias_act16(acc[g * 4][mi], acc[g * 4 + 1][mi], acc[g * 4 + 2][mi], acc[g * 4 + 3][mi], bv, a.act != 0, v);
             if (cbase + 16 <= a.Cout) {
                 f16* dst = reinterpret_cast<f16*>(a.out) + opix * a.out_ct + a.out_coff + cbase;
                 if (a.res) {
@@ -1924,13 +1994,10 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemArgs a, const 
         }
         if (pv) {
             f16x8 o0, o1;
+            float v16[16];
+            bias_act16(acc[0], acc[1], acc[2], acc[3], bv, true, v16);
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float v = silu_fast(acc[ni][j] + bv[ni * 4 + j]);
-                    if (ni < 2) o0[ni * 4 + j] = (f16)v; else o1[(ni - 2) * 4 + j] = (f16)v;
-                }
+            for (int j = 0; j < 8; ++j) { o0[j] = (f16)v16[j]; o1[j] = (f16)v16[8 + j]; }
             f16* dst = reinterpret_cast<f16*>(a.out) + pix * a.out_ct + a.out_coff + fq * 16;
             *reinterpret_cast<f16x8*>(dst) = o0;
             *reinterpret_cast<f16x8*>(dst + 8) = o1;
@@ -2067,13 +2134,10 @@ __global__ __launch_bounds__(512) void stem_down_kernel(const StemDownArgs a) {
                 acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sw1[ni], x1, acc[ni], 0, 0, 0);
             }
             f16x8 o0, o1;
+            float v16[16];
+            bias_act16(acc[0], acc[1], acc[2], acc[3], bv, true, v16);
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float v = silu_fast(acc[ni][j] + bv[ni * 4 + j]);
-                    if (ni < 2) o0[ni * 4 + j] = (f16)v; else o1[(ni - 2) * 4 + j] = (f16)v;
-                }
+            for (int j = 0; j < 8; ++j) { o0[j] = (f16)v16[j]; o1[j] = (f16)v16[8 + j]; }
             const unsigned keep = inmap ? 0xFFFFFFFFu : 0u;   // a select on the packed result: a `?:` around silu becomes 16 branches
             const u32x4 k4 = {keep, keep, keep, keep};
             char* row = smem + p * 128;
@@ -2121,13 +2185,10 @@ __global__ __launch_bounds__(512) void stem_down_kernel(const StemDownArgs a) {
         if (oy >= a.Ho || ox >= a.Wo || (a.dbg & 4)) continue;
         const long pix = ((long)b * a.Ho + oy) * a.Wo + ox;
         f16x8 o0, o1;
+        float v16[16];
+        bias_act16(acc[0][m], acc[1][m], acc[2][m], acc[3][m], bv, true, v16);
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float v = silu_fast(acc[ni][m][j] + bv[ni * 4 + j]);
-                if (ni < 2) o0[ni * 4 + j] = (f16)v; else o1[(ni - 2) * 4 + j] = (f16)v;
-            }
+        for (int j = 0; j < 8; ++j) { o0[j] = (f16)v16[j]; o1[j] = (f16)v16[8 + j]; }
         f16* dst = reinterpret_cast<f16*>(a.out) + pix * a.out_ct + a.out_coff + cbase;
         *reinterpret_cast<f16x8*>(dst) = o0;
         *reinterpret_cast<f16x8*>(dst + 8) = o1;

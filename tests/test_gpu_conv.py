@@ -41,6 +41,8 @@ CASES = [  # B, H, W, Cin, Cout, k, s, act, residual
     (4, 14, 15, 128, 192, 3, 1, True, False),     # dual-image variant, ragged 14x15 maps, Cout 192 (box head), two slab pairs
     (16, 128, 128, 128, 128, 3, 2, True, False),  # pixels-direct kernel, 3x3 stride 2 (taps as uniform address shifts), 128-ch tile
     (5, 130, 126, 128, 320, 3, 2, True, False),   # pixels-direct 3x3 s2: odd rows/cols at the border, ragged 256-ch tiles, 18 K chunks
+    (70, 64, 64, 64, 64, 3, 1, True, True),       # persistent 64-channel kernel: 4-5 patches per workgroup (both wave groups, odd and even counts), residual
+    (33, 40, 72, 64, 64, 3, 1, True, False),      # persistent 64-channel kernel: ragged patches, 1-2 patches per workgroup
 ]
 
 
