@@ -1387,6 +1387,14 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
     // workgroup per CU walking the patches with the next patch's halo / first weight stages requested behind the last stage
     // barrier so that their round trip runs under the epilogue: 7807 vs 7851 tiles/s with the same restructured body, which
     // itself cost 2.5 % through spills at the 256-VGPR limit -- the exposed prologue is not where the time goes)
+    // the workgroup's BN bias values go to LDS with the very first request (wave 0; it is the oldest of that wave's requests,
+    // so every counted wait below covers it): the epilogue then reads them in ~100 cycles instead of paying an exposed L2
+    // round trip per workgroup (one workgroup per CU: nothing else would hide it)
+    float* const bias_lds = reinterpret_cast<float*>(smem + 2 * P_BYTES + RING * W_BYTES);
+    if (wave == 0) {
+        const auto rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, (unsigned)pad64(a.Cout) * 4u, 0x00020000);
+        dma_piece(rsb, (lds_ptr_t*)bias_lds, lane * 16 < BN * 4 ? (unsigned)(n0 * 4 + lane * 16) : CY_OOB, 0);
+    }
     // prologue: halo of slab 0, weight stages 0 and 1
     dma_patch(0, 0);
     dma_stage(0, 0, 0);
@@ -1450,7 +1458,10 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
     }
     float bv[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) bv[j] = a.bias[cbase + j];
+    for (int j = 0; j < 4; ++j) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(bias_lds + wn * 64 + fq * 16 + j * 4);
+        bv[j * 4] = t[0]; bv[j * 4 + 1] = t[1]; bv[j * 4 + 2] = t[2]; bv[j * 4 + 3] = t[3];
+    }
 #pragma unroll
     for (int mi = 0; mi < MIW; ++mi) {
         const int y = y0 + wm * RPW + (mi >> 1), x = DUAL ? fr : x0 + (mi & 1) * 16 + fr;
@@ -1486,7 +1497,7 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
 template <int WN, bool DUAL = false, int TPS = 2>
 static hipError_t launch_wide(const ConvArgs& a, hipStream_t s) {
     constexpr int PR = 18 * (DUAL ? 36 : 34), NPC = (PR + 15) / 16, PROUNDS = (NPC + 7) / 8, BN = 64 * WN;
-    const size_t lds = 2 * PROUNDS * 8 * 1024 + 3 * TPS * BN * 64;
+    const size_t lds = 2 * PROUNDS * 8 * 1024 + 3 * TPS * BN * 64 + 1024;       // halo x2, weight ring, bias
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wide_kernel<false, WN, DUAL, TPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1632,6 +1643,13 @@ __global__ __launch_bounds__(512, (NB * MI <= 4 && RING == 2) ? 2 : 1) void conv
         }
     };
 
+    // the tile's BN bias values -> LDS with the very first request (wave 0; oldest request: every counted wait covers it), so
+    // that the epilogue does not start with an exposed L2 round trip
+    float* const bias_lds = reinterpret_cast<float*>(smem + RING * W_BYTES);
+    if (wave == 0) {
+        const auto rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, (unsigned)pad64(a.Cout) * 4u, 0x00020000);
+        dma_piece(rsb, (lds_ptr_t*)bias_lds, lane * 16 < BN * 4 ? (unsigned)(n0 * 4 + lane * 16) : CY_OOB, 0);
+    }
     // prologue: chunks 0..DIST-1 requested (weights first, then pixels, per chunk: the order the counted waits assume)
 #pragma unroll
     for (int d = 0; d < DIST; ++d)
@@ -1668,7 +1686,10 @@ __global__ __launch_bounds__(512, (NB * MI <= 4 && RING == 2) ? 2 : 1) void conv
         if (cbase >= pad64(a.Cout)) continue;
         float bv[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) bv[j] = a.bias[cbase + j];
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(bias_lds + g * 64 + fq * 16 + j * 4);
+            bv[j * 4] = t[0]; bv[j * 4 + 1] = t[1]; bv[j * 4 + 2] = t[2]; bv[j * 4 + 3] = t[3];
+        }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int m = m0 + (wave * MI + mi) * 16 + fr;
@@ -1707,7 +1728,7 @@ __global__ __launch_bounds__(512, (NB * MI <= 4 && RING == 2) ? 2 : 1) void conv
 template <int NB, int MI, int RING, bool K3>
 static hipError_t launch_direct(const ConvArgs& a, hipStream_t s) {
     constexpr int BN = 64 * NB, BM = 8 * MI * 16;
-    const size_t lds = RING * BN * 128;
+    const size_t lds = RING * BN * 128 + 1024;             // weight ring, bias
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_direct_kernel<NB, MI, RING, K3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
