@@ -366,7 +366,10 @@ def run_rank(args):
                                                       "2 x FETCH + WRITE; not measured in this run)" % tsrc) if tsrc else None,
                                    "flops_per_launch": k["flops"] / k["launches"],
                                    "avg_launch_ms": k["ms"] / k["launches"], "launches": k["launches"],
-                                   "timing": "hipEvents around every launch of every second batch on the launch stream, over the timed region (rank 0)"}
+                                   "timing": "hipEvents around every launch of every second batch on the launch stream, over the timed region (rank 0)"
+                                             + ("; batches of 64..239 tiles run their forward as two concurrent half-batches on two streams, so the "
+                                                "launches timed here overlap each other and `achieved` understates the kernel's exclusive rate by up to 2x"
+                                                if 64 <= batch < 240 else "")}
             tot_ms = sum(p["ms"] for p in prof)
             out["forward_kernels"] = [{"kernel": p["kernel"], "ms_total": p["ms"], "launches": p["launches"],
                                        "TFLOP/s": (p["flops"] / (p["ms"] * 1e-3) / 1e12) if p["ms"] > 0 else 0.0,
