@@ -1257,6 +1257,8 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
     const int b = rest / tiles_y;
     const int y0 = ty * TH, x0 = tx * TW, n0 = nt * BN;
     const int pairs = a.Cin / 64;                           // pairs of 32-channel slabs
+    const bool stamps = CY_STAMPS_ENABLED && (a.dbg & 64) != 0;      // diagnostic builds: phase stamps of the workgroup
+    const unsigned long long t_entry = stamps ? stamp_now() : 0;
 
     const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in0), 0, a.in0_bytes, 0x00020000);
     const auto rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wgt32), 0, a.wgt32_bytes, 0x00020000);
@@ -1382,6 +1384,10 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
         }
     };
 
+    // Workgroup time over the layers of the benchmark: ~12 us + 1.35 us per stage (18 / 36 / 72 stages: 36 / 60 / 110 us), i.e. a third of
+    // an 18-stage workgroup is launch + prologue round trip + epilogue (128 SiLUs per lane at 26 issue cycles each, two waves per
+    // SIMD) + stores.  Starting the first round of workgroups in 2 / 4 / 8 phases a fraction of a workgroup apart (so that the CUs'
+    // read and write bursts stop coinciding) only added the idle time it cost: +4.4 / +6.4 / +6.6 % on the forward pass.
     // (tried in round 2, not kept: s_setprio 1 for waves 4-7 before the loop -- static priority for the second-dispatched half,
     // MI355X_MICROARCH.md "Two waves per SIMD" item 4: 8026 vs 8048 tiles/s on the S16k benchmark; and a PERSISTENT form, one
     // workgroup per CU walking the patches with the next patch's halo / first weight stages requested behind the last stage
@@ -1401,6 +1407,7 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
     dma_stage(1, 0, TPS);
     CY_WAIT_VM(WPS);
     __builtin_amdgcn_s_barrier();
+    const unsigned long long t_loop = stamps ? stamp_now() : 0;
 #pragma unroll 1
     for (int cp = 0; cp < pairs; ++cp) {
         const bool more = cp + 1 < pairs;
@@ -1438,6 +1445,7 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
         }
     }
 
+    const unsigned long long t_epi = stamps ? stamp_now() : 0;
     const int cbase = n0 + wn * 64 + fq * 16;
     // Residual (bottleneck shortcut): all of this wave's 2*MIW vectors are requested up front (the fragment registers are
     // free now), so the epilogue pays ONE memory round trip instead of one per pixel fragment (1 workgroup per CU: nothing
@@ -1490,6 +1498,16 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
                 if (a.res) t += (float)(reinterpret_cast<const f16*>(a.res)[pix * a.res_ct + a.res_coff + c]);
                 reinterpret_cast<f16*>(a.out)[pix * a.out_ct + a.out_coff + c] = (f16)t;
             }
+        }
+    }
+    if (stamps) {       // [0] entry -> loop (address setup, prologue round trip), [1] loop, [2] epilogue issue, [3] stores drained, [4] total, [5] stages, [6] waves
+        const unsigned long long t_st = stamp_now();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t_end = stamp_now();
+        if (lane == 0) {
+            atomicAdd(&g_stamps[0], t_loop - t_entry); atomicAdd(&g_stamps[1], t_epi - t_loop); atomicAdd(&g_stamps[2], t_st - t_epi);
+            atomicAdd(&g_stamps[3], t_end - t_st); atomicAdd(&g_stamps[4], t_end - t_entry); atomicAdd(&g_stamps[5], (unsigned long long)(pairs * NST));
+            atomicAdd(&g_stamps[6], 1ull);
         }
     }
 }
@@ -1858,7 +1876,8 @@ hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s) {
         case CONV_GENERIC_BIG: return launch_t<f16, 4, 2, 4, 3>(a, s);
         case CONV_WIDE_128: {
             static const int tps = getenv("CY_WIDE_TPS") ? atoi(getenv("CY_WIDE_TPS")) : 2;
-            return tps == 3 ? launch_wide<2, false, 3>(a, s) : launch_wide<2>(a, s);
+            ConvArgs b2 = a; b2.dbg = dev_knob("CY_DBG", 0);
+            return tps == 3 ? launch_wide<2, false, 3>(b2, s) : launch_wide<2>(b2, s);
         }
         case CONV_WIDE_64: return launch_wide<1>(a, s);
         case CONV_WIDE_DUAL: return launch_wide<2, true>(a, s);
