@@ -132,8 +132,16 @@ class MosaicSource(object):
         for a0, a1, b0, b1, t in self.regions:
             if a0 <= x0 and x1 <= a1 and b0 <= y0 and y1 <= b1:
                 return t, a0, b0
-        arr = np.ascontiguousarray(self.host[y0:y1, x0:x1])
-        t = det.mosaic_to_device(arr, big_endian=self.big_endian)
+        file_rows = None
+        if (isinstance(self.host, np.memmap) and self.host.dtype.itemsize == 4 and getattr(self.host, "filename", None)
+                and (x1 - x0) * 10 >= 9 * self.nx):
+            # (nearly) full-width band of a memory-mapped file: take whole rows, which are one contiguous run of the file, and
+            # read them with pread() straight into the upload's pinned buffers (faulting the map in page by page took as
+            # long as the transfer itself)
+            x0, x1 = 0, self.nx
+            file_rows = (str(self.host.filename), int(self.host.offset) + y0 * self.nx * 4)
+        arr = self.host[y0:y1, x0:x1]                       # a view: the upload copies it chunk by chunk
+        t = det.mosaic_to_device(arr, big_endian=self.big_endian, file_rows=file_rows)
         self.regions.append((x0, x1, y0, y1, t))
         self.bytes_uploaded += arr.size * 4
         return t, x0, y0

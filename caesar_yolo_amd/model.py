@@ -68,6 +68,9 @@ class HipDetector(object):
         nc = self.lib.cy_num_classes(self.ctx)
         self.names = {i: self.lib.cy_class_name(self.ctx, i).decode() for i in range(nc)}
         self.nc = nc
+        # pinned staging buffers of the mosaic upload: part of the context (the first pinned allocation of a process costs
+        # ~110 ms of runtime initialisation, which belongs here and not in the first image's ingest)
+        self._stage = [torch.empty((self.STAGE_BYTES // 4,), dtype=torch.int32, pin_memory=True) for _ in range(2)]
 
     def close(self):
         if getattr(self, "ctx", None):
@@ -92,17 +95,68 @@ class HipDetector(object):
         return L.check(rc, self.ctx)
 
     # ---- stages
-    def mosaic_to_device(self, data, big_endian=None):
-        """Host fp32 image [H,W] (either byte order) -> resident device mosaic with read_fits value semantics."""
+    def mosaic_to_device(self, data, big_endian=None, file_rows=None):
+        """Host fp32 image [H,W] (either byte order) -> resident device mosaic with read_fits value semantics.
+        file_rows = (path, byte offset of the first row of `data` in that file): `data` is a run of whole rows of a memory-mapped
+        file; a large one is then read with pread() straight into the pinned staging buffers (no page faults on the map)."""
         arr = np.asarray(data)
         if arr.dtype.kind != "f" or arr.dtype.itemsize != 4:
             arr = arr.astype("<f4")
         if big_endian is None:
             big_endian = arr.dtype.byteorder == ">"
-        raw = np.ascontiguousarray(arr).view(np.uint32).view(np.int32)
-        t = torch.from_numpy(raw.copy() if not raw.flags.writeable else raw).to(self.tdev).view(torch.float32)
+        if arr.ndim == 2 and arr.nbytes >= self.STAGED_UPLOAD_MIN_BYTES:
+            t = self._staged_upload(arr, file_rows)
+        else:
+            raw = np.ascontiguousarray(arr).view(np.uint32).view(np.int32)
+            t = torch.from_numpy(raw.copy() if not raw.flags.writeable else raw).to(self.tdev).view(torch.float32)
         self._chk(self.lib.cy_mosaic_prepare(self.ctx, self._p(t), t.numel(), int(bool(big_endian)), self._stream()))
         return t
+
+    STAGED_UPLOAD_MIN_BYTES = 64 << 20
+    STAGE_BYTES = 32 << 20
+    STAGE_THREADS = 4
+
+    def _staged_upload(self, arr, file_rows=None):
+        """Large host image (typically a slice of the memory-mapped FITS payload, file byte order) -> device, in row chunks
+        through two pinned staging buffers: filling chunk i+1 (several threads: pread() of the file when the rows are whole
+        rows of it, else numpy copies out of the map; both release the GIL) runs while chunk i is on the wire."""
+        from concurrent.futures import ThreadPoolExecutor
+        H, Wd = arr.shape
+        fd = os.open(file_rows[0], os.O_RDONLY) if file_rows else -1
+        out = torch.empty((H, Wd), dtype=torch.int32, device=self.tdev)
+        rows = max(1, min(H, self.STAGE_BYTES // (Wd * 4)))
+        if getattr(self, "_stage", None) is None or self._stage[0].numel() < rows * Wd:         # (a single row wider than a buffer)
+            self._stage = [torch.empty((rows * Wd,), dtype=torch.int32, pin_memory=True) for _ in range(2)]
+        views = [st[:rows * Wd].view(rows, Wd).numpy().view(arr.dtype) for st in self._stage]      # same item size: a raw byte copy
+        done = [None, None]
+        nthr = self.STAGE_THREADS
+        with ThreadPoolExecutor(nthr) as pool:
+            for i, y in enumerate(range(0, H, rows)):
+                k = i & 1
+                if done[k] is not None:
+                    done[k].synchronize()                        # the previous transfer out of this buffer has finished
+                n = min(rows, H - y)
+                cuts = [n * j // nthr for j in range(nthr + 1)]
+                if fd >= 0:
+                    def fill(j, k=k, y=y, cuts=cuts):
+                        if cuts[j + 1] > cuts[j]:
+                            buf = memoryview(views[k][cuts[j]:cuts[j + 1]]).cast("B")
+                            got = os.preadv(fd, [buf], file_rows[1] + (y + cuts[j]) * Wd * 4)
+                            if got != len(buf):
+                                raise L.CyError("short read of %s" % (file_rows[0],))
+                else:
+                    def fill(j, k=k, y=y, cuts=cuts):
+                        np.copyto(views[k][cuts[j]:cuts[j + 1]], arr[y + cuts[j]:y + cuts[j + 1]])
+                list(pool.map(fill, range(nthr)))
+                out[y:y + n].copy_(self._stage[k][:n * Wd].view(n, Wd), non_blocking=True)
+                done[k] = torch.cuda.Event()
+                done[k].record()
+        for e in done:
+            if e is not None:
+                e.synchronize()
+        if fd >= 0:
+            os.close(fd)
+        return out.view(torch.float32)
 
     def preproc(self, mosaic, tiles_xy, th, tw, imgsz, cfg):
         B = len(tiles_xy)

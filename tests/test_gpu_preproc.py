@@ -213,3 +213,56 @@ def test_preprocessed_image_matches_reference_golden_fp64(pname, iname):
         got = got[:, :, 0]
     assert np.array_equal(got == 0, ref == 0)
     np.testing.assert_allclose(got, ref, rtol=1e-10, atol=1e-13)
+
+
+def test_staged_upload_of_a_memory_map_slice(tmp_path, monkeypatch):
+    """The chunked upload through pinned staging buffers (used for large images, here forced on a small one) gives the same
+    resident mosaic as the plain upload: a non-contiguous slice of a big-endian memory map, several chunks per buffer, a
+    last chunk that is shorter, NaN / inf -> 0 (utils.read_fits value semantics, caesar_yolo/utils.py:219, :394)."""
+    from caesar_yolo_amd.model import HipDetector
+    det = detector("fp32")
+    rng = np.random.default_rng(5)
+    full = rng.standard_normal((700, 900)).astype(">f4")
+    full[3, 7] = np.nan
+    full[650, 880] = np.inf
+    path = tmp_path / "m.bin"
+    full.tofile(path)
+    mm = np.memmap(path, dtype=">f4", mode="r", shape=full.shape)
+    view = mm[11:688, 5:893]                                   # 677 x 888: not contiguous
+    plain = det.mosaic_to_device(np.ascontiguousarray(view), big_endian=True).cpu().numpy()
+    monkeypatch.setattr(HipDetector, "STAGED_UPLOAD_MIN_BYTES", 1 << 10)
+    monkeypatch.setattr(HipDetector, "STAGE_BYTES", 100 * 888 * 4)      # 100 rows per chunk -> 7 chunks, the last of 77 rows
+    det._stage = None
+    staged = det.mosaic_to_device(view, big_endian=True).cpu().numpy()
+    det._stage = None
+    want = np.nan_to_num(view.astype("<f4"), nan=0.0, posinf=0.0, neginf=0.0)
+    assert staged.shape == want.shape
+    assert np.array_equal(staged, want)
+    assert np.array_equal(staged, plain)
+
+
+def test_staged_upload_reads_whole_rows_with_pread(tmp_path, monkeypatch):
+    """MosaicSource on a memory-mapped FITS payload: a (nearly) full-width band is widened to whole rows and read with pread()
+    into the pinned buffers; the resident region equals the plain upload of the same rows and the origin is rebased."""
+    from caesar_yolo_amd.model import HipDetector
+    from caesar_yolo_amd.inference import MosaicSource
+    from caesar_yolo_amd import utils
+    det = detector("fp32")
+    rng = np.random.default_rng(6)
+    img = rng.standard_normal((300, 640)).astype(np.float32)
+    img[5, 5] = np.nan
+    path = str(tmp_path / "m.fits")
+    utils.write_fits_image(path, img, {})
+    data, _ = utils.read_fits_image(path)
+    assert isinstance(data, np.memmap)
+    monkeypatch.setattr(HipDetector, "STAGED_UPLOAD_MIN_BYTES", 1 << 10)
+    monkeypatch.setattr(HipDetector, "STAGE_BYTES", 64 * 640 * 4)
+    det._stage = None
+    src = MosaicSource(data)
+    t, ox, oy = src.region(det, 0, 600, 17, 290)               # 600 of 640 columns: widened to whole rows
+    det._stage = None
+    assert (ox, oy) == (0, 17) and tuple(t.shape) == (273, 640)
+    want = np.nan_to_num(img[17:290], nan=0.0)
+    assert np.array_equal(t.cpu().numpy(), want)
+    t2, ox2, oy2 = src.region(det, 100, 300, 20, 200)           # inside the resident region: reused
+    assert t2 is t and (ox2, oy2) == (0, 17)

@@ -151,7 +151,7 @@ def test_mosaic_source_uploads_only_the_ranks_regions(world):
         def __init__(self):
             self.calls = []
 
-        def mosaic_to_device(self, arr, big_endian=None):
+        def mosaic_to_device(self, arr, big_endian=None, file_rows=None):
             return torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32))
 
         def detect_tiles(self, img, xy, th, tw, imgsz, cfg, conf, iou, soft, hard, out=None, flush=True):
