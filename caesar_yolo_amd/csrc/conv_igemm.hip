@@ -39,9 +39,16 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define CY_STAMPS_ENABLED 0
 #endif
 __device__ unsigned long long g_stamps[8];
+constexpr int WG_STAMP_SLOTS = 4096;
+__device__ unsigned long long g_wg_stamps[WG_STAMP_SLOTS * 4];     // per-workgroup phase records of the wide kernel (stamped builds)
 __device__ __forceinline__ unsigned long long stamp_now() {
     unsigned long long t;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+__device__ __forceinline__ unsigned long long stamp_real() {       // constant 100 MHz counter: wall time in units of 10 ns
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
     return t;
 }
 
@@ -1258,7 +1265,7 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
     const int y0 = ty * TH, x0 = tx * TW, n0 = nt * BN;
     const int pairs = a.Cin / 64;                           // pairs of 32-channel slabs
     const bool stamps = CY_STAMPS_ENABLED && (a.dbg & 64) != 0;      // diagnostic builds: phase stamps of the workgroup
-    const unsigned long long t_entry = stamps ? stamp_now() : 0;
+    const unsigned long long t_entry = stamps ? stamp_real() : 0;
 
     const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in0), 0, a.in0_bytes, 0x00020000);
     const auto rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wgt32), 0, a.wgt32_bytes, 0x00020000);
@@ -1388,6 +1395,13 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
     // an 18-stage workgroup is launch + prologue round trip + epilogue (128 SiLUs per lane at 26 issue cycles each, two waves per
     // SIMD) + stores.  Starting the first round of workgroups in 2 / 4 / 8 phases a fraction of a workgroup apart (so that the CUs'
     // read and write bursts stop coinciding) only added the idle time it cost: +4.4 / +6.4 / +6.6 % on the forward pass.
+    // Phase records of a stamped build (tools/stamp_wide.py, 256 tiles): 18-stage workgroups (Cin 128, 64x64 maps) spend 3.7 us before
+    // the loop, 24.9 us in it (1.39 us per stage), 3.2 us issuing the epilogue (6.9 us with a residual input) and 0.7 us draining
+    // stores = 32.6 us of a 36.2 us slot (the rest is the hand-over between workgroups); 36-stage ones 2.3 + 49.5 + 3.2 + 0.7 of 60.
+    // A PERSISTENT form was tried a second time with those figures in hand (one workgroup per CU walking patches, the next patch's
+    // bias / halo / first two weight stages requested right behind the last stage barrier so that they land under the epilogue,
+    // residual vectors as a ring of four fragments to stay inside 256 VGPRs): 28.9-29.0 ms forward against 28.0, every layer
+    // slower (residual layers +14 %).  The hardware's own hand-over between one-patch workgroups is the better pipeline here.
     // (tried in round 2, not kept: s_setprio 1 for waves 4-7 before the loop -- static priority for the second-dispatched half,
     // MI355X_MICROARCH.md "Two waves per SIMD" item 4: 8026 vs 8048 tiles/s on the S16k benchmark; and a PERSISTENT form, one
     // workgroup per CU walking the patches with the next patch's halo / first weight stages requested behind the last stage
@@ -1407,7 +1421,7 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
     dma_stage(1, 0, TPS);
     CY_WAIT_VM(WPS);
     __builtin_amdgcn_s_barrier();
-    const unsigned long long t_loop = stamps ? stamp_now() : 0;
+    const unsigned long long t_loop = stamps ? stamp_real() : 0;
 #pragma unroll 1
     for (int cp = 0; cp < pairs; ++cp) {
         const bool more = cp + 1 < pairs;
@@ -1445,7 +1459,7 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
         }
     }
 
-    const unsigned long long t_epi = stamps ? stamp_now() : 0;
+    const unsigned long long t_epi = stamps ? stamp_real() : 0;
     const int cbase = n0 + wn * 64 + fq * 16;
     // Residual (bottleneck shortcut): all of this wave's 2*MIW vectors are requested up front (the fragment registers are
     // free now), so the epilogue pays ONE memory round trip instead of one per pixel fragment (1 workgroup per CU: nothing
@@ -1500,14 +1514,16 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
             }
         }
     }
-    if (stamps) {       // [0] entry -> loop (address setup, prologue round trip), [1] loop, [2] epilogue issue, [3] stores drained, [4] total, [5] stages, [6] waves
-        const unsigned long long t_st = stamp_now();
+    // diagnostic builds: one record per workgroup (wave 0, plain stores; units of 10 ns): [0] entry -> loop (address setup, prologue
+    // round trip), [1] stage loop, [2] epilogue issue, [3] store drain.  (Summing with atomics from 16k waves stretched the
+    // kernel 4x and the epilogue figures with it.)
+    if (stamps) {
+        const unsigned long long t_st = stamp_real();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long t_end = stamp_now();
-        if (lane == 0) {
-            atomicAdd(&g_stamps[0], t_loop - t_entry); atomicAdd(&g_stamps[1], t_epi - t_loop); atomicAdd(&g_stamps[2], t_st - t_epi);
-            atomicAdd(&g_stamps[3], t_end - t_st); atomicAdd(&g_stamps[4], t_end - t_entry); atomicAdd(&g_stamps[5], (unsigned long long)(pairs * NST));
-            atomicAdd(&g_stamps[6], 1ull);
+        const unsigned long long t_end = stamp_real();
+        if (tid == 0) {
+            unsigned long long* rec = g_wg_stamps + (size_t)(blockIdx.x % WG_STAMP_SLOTS) * 4;
+            rec[0] = t_loop - t_entry; rec[1] = t_epi - t_loop; rec[2] = t_st - t_epi; rec[3] = t_end - t_st;
         }
     }
 }
@@ -1902,6 +1918,14 @@ hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s) {
 void debug_read_stamps(unsigned long long* out8, bool reset) {
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stamps), 8 * sizeof(unsigned long long));
+    if (CY_STAMPS_ENABLED && out8[6] == 0) {        // no summed stamps: average the wide kernel's per-workgroup records instead
+        static unsigned long long rec[WG_STAMP_SLOTS * 4];
+        hipMemcpyFromSymbol(rec, HIP_SYMBOL(g_wg_stamps), sizeof(rec));
+        for (int i = 0; i < WG_STAMP_SLOTS; ++i)
+            if (rec[i * 4 + 1]) { out8[6] += 1; for (int j = 0; j < 4; ++j) out8[j] += rec[i * 4 + j]; }
+        out8[4] = out8[0] + out8[1] + out8[2] + out8[3];
+        if (reset) { memset(rec, 0, sizeof(rec)); hipMemcpyToSymbol(HIP_SYMBOL(g_wg_stamps), rec, sizeof(rec)); }
+    }
     if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)); }
 }
 

@@ -23,5 +23,7 @@ for i in range(5):
     det.conv_bn_silu(x, w, b, 3, 1, True, res)
 L.load().cy_debug_stamps(st, 0)
 pro, loop, epi, drain, tot, stages, waves = [float(st[i]) for i in range(7)]
-print("waves %d, stages/wave %.0f; s_memtime ticks per wave: entry->loop %.0f | loop %.0f (%.0f per stage) | epilogue issue %.0f | store drain %.0f | total %.0f"
-      % (waves, stages / waves, pro / waves, loop / waves, loop / stages, epi / waves, drain / waves, tot / waves))
+stages = waves * (Cin // 64) * 9     # records are per workgroup (wave 0)
+u = 0.01   # s_memrealtime: 100 MHz
+print("workgroups sampled %d, stages %.0f; us per workgroup: entry->loop %.2f | loop %.2f (%.3f per stage) | epilogue issue %.2f | store drain %.2f | total %.2f"
+      % (waves, stages / waves, u * pro / waves, u * loop / waves, u * loop / stages, u * epi / waves, u * drain / waves, u * tot / waves))
