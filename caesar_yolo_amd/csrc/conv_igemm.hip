@@ -1402,6 +1402,11 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
     // bias / halo / first two weight stages requested right behind the last stage barrier so that they land under the epilogue,
     // residual vectors as a ring of four fragments to stay inside 256 VGPRs): 28.9-29.0 ms forward against 28.0, every layer
     // slower (residual layers +14 %).  The hardware's own hand-over between one-patch workgroups is the better pipeline here.
+    // A STAGGERED form was tried as well (MI355X_MICROARCH.md "Two waves per SIMD" item 9: waves 4-7 half a stage behind waves 0-3 --
+    // between two barriers 16 + 48 MFMAs of two stages for the first group, 32 + 32 for the second; four-slot weight ring addressed
+    // at run time, odd halo slab requested a stage later; one stage loop per group, else the two streams cost 580 B of scratch;
+    // bit-identical outputs): 29.10 vs 28.79-28.98 ms forward on the same box, 18-stage layers 5 % slower, 36- and 72-stage layers
+    // unchanged.  So the 1.39 us per stage (74 % of the MFMA issue rate at 2.0 GHz) is not a lock-step effect either.
     // (tried in round 2, not kept: s_setprio 1 for waves 4-7 before the loop -- static priority for the second-dispatched half,
     // MI355X_MICROARCH.md "Two waves per SIMD" item 4: 8026 vs 8048 tiles/s on the S16k benchmark; and a PERSISTENT form, one
     // workgroup per CU walking the patches with the next patch's halo / first weight stages requested behind the last stage
