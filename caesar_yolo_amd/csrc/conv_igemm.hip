@@ -1406,7 +1406,9 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
     // between two barriers 16 + 48 MFMAs of two stages for the first group, 32 + 32 for the second; four-slot weight ring addressed
     // at run time, odd halo slab requested a stage later; one stage loop per group, else the two streams cost 580 B of scratch;
     // bit-identical outputs): 29.10 vs 28.79-28.98 ms forward on the same box, 18-stage layers 5 % slower, 36- and 72-stage layers
-    // unchanged.  So the 1.39 us per stage (74 % of the MFMA issue rate at 2.0 GHz) is not a lock-step effect either.
+    // unchanged.  So the 1.39 us per stage is not a lock-step effect either.  It is the clock: s_memtime / s_memrealtime over the loop
+    // give 1.76 GHz for 18-, 36- and 72-stage layers, at which a stage's 2 x 64 MFMAs per SIMD (2048 cycles) would take 1.16 us:
+    // the loop runs at 84 % of the matrix-core rate at the clock the chip holds under this load.
     // (tried in round 2, not kept: s_setprio 1 for waves 4-7 before the loop -- static priority for the second-dispatched half,
     // MI355X_MICROARCH.md "Two waves per SIMD" item 4: 8026 vs 8048 tiles/s on the S16k benchmark; and a PERSISTENT form, one
     // workgroup per CU walking the patches with the next patch's halo / first weight stages requested behind the last stage
@@ -1426,7 +1428,7 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
     dma_stage(1, 0, TPS);
     CY_WAIT_VM(WPS);
     __builtin_amdgcn_s_barrier();
-    const unsigned long long t_loop = stamps ? stamp_real() : 0;
+    const unsigned long long t_loop = stamps ? stamp_real() : 0, c_loop = stamps ? stamp_now() : 0;
 #pragma unroll 1
     for (int cp = 0; cp < pairs; ++cp) {
         const bool more = cp + 1 < pairs;
@@ -1464,7 +1466,7 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
         }
     }
 
-    const unsigned long long t_epi = stamps ? stamp_real() : 0;
+    const unsigned long long t_epi = stamps ? stamp_real() : 0, c_epi = stamps ? stamp_now() : 0;
     const int cbase = n0 + wn * 64 + fq * 16;
     // Residual (bottleneck shortcut): all of this wave's 2*MIW vectors are requested up front (the fragment registers are
     // free now), so the epilogue pays ONE memory round trip instead of one per pixel fragment (1 workgroup per CU: nothing
@@ -1520,7 +1522,7 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
         }
     }
     // diagnostic builds: one record per workgroup (wave 0, plain stores; units of 10 ns): [0] entry -> loop (address setup, prologue
-    // round trip), [1] stage loop, [2] epilogue issue, [3] store drain.  (Summing with atomics from 16k waves stretched the
+    // round trip), [1] stage loop, [2] epilogue issue, [3] the stage loop again in s_memtime ticks (clock = [3] / [1]).  (Summing with atomics from 16k waves stretched the
     // kernel 4x and the epilogue figures with it.)
     if (stamps) {
         const unsigned long long t_st = stamp_real();
@@ -1528,7 +1530,7 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
         const unsigned long long t_end = stamp_real();
         if (tid == 0) {
             unsigned long long* rec = g_wg_stamps + (size_t)(blockIdx.x % WG_STAMP_SLOTS) * 4;
-            rec[0] = t_loop - t_entry; rec[1] = t_epi - t_loop; rec[2] = t_st - t_epi; rec[3] = t_end - t_st;
+            rec[0] = t_loop - t_entry; rec[1] = t_epi - t_loop; rec[2] = t_st - t_epi; rec[3] = c_epi - c_loop;   // [3]: the loop in s_memtime ticks
         }
     }
 }

@@ -25,5 +25,5 @@ L.load().cy_debug_stamps(st, 0)
 pro, loop, epi, drain, tot, stages, waves = [float(st[i]) for i in range(7)]
 stages = waves * (Cin // 64) * 9     # records are per workgroup (wave 0)
 u = 0.01   # s_memrealtime: 100 MHz
-print("workgroups sampled %d, stages %.0f; us per workgroup: entry->loop %.2f | loop %.2f (%.3f per stage) | epilogue issue %.2f | store drain %.2f | total %.2f"
-      % (waves, stages / waves, u * pro / waves, u * loop / waves, u * loop / stages, u * epi / waves, u * drain / waves, u * tot / waves))
+print("workgroups sampled %d, stages %.0f; us per workgroup: entry->loop %.2f | loop %.2f (%.3f per stage) | epilogue issue %.2f | s_memtime ticks per us in the loop %.0f | total %.2f"
+      % (waves, stages / waves, u * pro / waves, u * loop / waves, u * loop / stages, u * epi / waves, drain / (u * loop), u * (pro + loop + epi) / waves))
