@@ -1567,6 +1567,8 @@ __global__ __launch_bounds__(512, (NB * MI <= 4 && RING == 2) ? 2 : 1) void conv
     constexpr int NW = 8, BN = 64 * NB, BM = NW * MI * 16, W_BYTES = BN * 128, DIST = RING - 1;
     constexpr int WPW = BN / 8 / NW, APW = 2 * MI, PER = WPW + APW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const bool stamps = CY_STAMPS_ENABLED && (a.dbg & 64) != 0;      // diagnostic builds: per-workgroup phase records (see the wide kernel)
+    const unsigned long long t_entry = stamps ? stamp_real() : 0;
     typedef __attribute__((address_space(3))) void lds_void;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1700,6 +1702,7 @@ __global__ __launch_bounds__(512, (NB * MI <= 4 && RING == 2) ? 2 : 1) void conv
     else if (DIST == 3 && chunks == 2) { CY_WAIT_VM(APW + PER); }
     else { CY_WAIT_VM(APW); }
     __builtin_amdgcn_s_barrier();
+    const unsigned long long t_loop = stamps ? stamp_real() : 0, c_loop = stamps ? stamp_now() : 0;
 #pragma unroll 1
     for (int cb = 0; cb < chunks; cb += RING) {
 #pragma unroll
@@ -1720,6 +1723,7 @@ __global__ __launch_bounds__(512, (NB * MI <= 4 && RING == 2) ? 2 : 1) void conv
         }
     }
 
+    const unsigned long long t_epi = stamps ? stamp_real() : 0, c_epi = stamps ? stamp_now() : 0;
     // ---- epilogue: per 64-channel block the same 16-contiguous-channels-per-lane layout as the other kernels
 #pragma unroll
     for (int g = 0; g < NB; ++g) {
@@ -1763,6 +1767,10 @@ __global__ __launch_bounds__(512, (NB * MI <= 4 && RING == 2) ? 2 : 1) void conv
                 }
             }
         }
+    }
+    if (stamps && tid == 0) {
+        unsigned long long* rec = g_wg_stamps + (size_t)(blockIdx.x % WG_STAMP_SLOTS) * 4;
+        rec[0] = t_loop - t_entry; rec[1] = t_epi - t_loop; rec[2] = stamp_real() - t_epi; rec[3] = c_epi - c_loop;
     }
 }
 
@@ -1905,12 +1913,13 @@ hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s) {
         case CONV_WIDE_64: return launch_wide<1>(a, s);
         case CONV_WIDE_DUAL: return launch_wide<2, true>(a, s);
         case CONV_DIRECT_256: {
+            ConvArgs a2 = a; a2.dbg = dev_knob("CY_DBG", 0);
             // tuning knob, off: 128 px x 256 ch tiles with two workgroups per CU for Cin <= CY_D256_V.  Measured at batch 256: 2-12 %
             // SLOWER on every 256-channel 1x1 layer but model.4.cv1 (-4 %): twice the weight pieces per MFMA cost more than the overlap buys
             static const int v256 = getenv("CY_D256_V") ? atoi(getenv("CY_D256_V")) : 0;
             if (a.k != 3 && v256 > 0 && a.Cin <= v256) return launch_direct<4, 1, 2, false>(a, s);
             // (a 4-slot ring for this tile: 256 VGPRs with spills, 3-10 % slower)
-            return a.k == 3 ? launch_direct<4, 2, 3, true>(a, s) : launch_direct<4, 2, 3, false>(a, s);
+            return a.k == 3 ? launch_direct<4, 2, 3, true>(a2, s) : launch_direct<4, 2, 3, false>(a2, s);
         }
         case CONV_DIRECT_128:     // strided 3x3 (model.1): 64 px per wave, so every weight fragment feeds four MFMAs (-8 % vs 32 px)
             // 1x1 with a 128-channel tile = the HBM-bound layers (model.2.cv1/cv2): two workgroups per CU (126 VGPRs, one chunk
