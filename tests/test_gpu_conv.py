@@ -82,6 +82,29 @@ def test_conv_bn_silu(prec, inv, case, monkeypatch):
     assert err <= tol, "max abs err %.3e > %.3e (scale %.2f)" % (err, tol, scale)
 
 
+@pytest.mark.parametrize("case", [(70, 64, 64, 64, 64, True), (33, 40, 72, 64, 64, False), (48, 64, 64, 32, 32, True),
+                                  (64, 64, 64, 128, 128, True), (40, 64, 64, 256, 256, False)])
+def test_two_group_and_ring_kernels_are_repeatable(case):
+    """Race screen for the kernels whose LDS hand-overs rest on counted waits and barriers alone (the two-group persistent
+    64-channel kernel, the wide kernel's weight ring, the pixels-direct ring): the same launch twenty times must give the same
+    bits every time -- a synchronisation slip shows as a rare wrong tile, not as a steady error."""
+    B, H, W, Cin, Cout, use_res = case
+    det = detector("fp16")
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    xd = torch.randn((B, H, W, Cin), generator=g).half().cuda()
+    rd = torch.randn((B, H, W, Cout), generator=g).half().cuda() if use_res else None
+    w = (torch.randn((Cout, Cin, 3, 3), generator=g) / (Cin * 9) ** 0.5).numpy()
+    b = (torch.randn((Cout,), generator=g) * 0.1).numpy()
+    first = det.conv_bn_silu(xd, w, b, 3, 1, True, rd)
+    for _ in range(20):
+        again = det.conv_bn_silu(xd, w, b, 3, 1, True, rd)
+        assert torch.equal(first, again)
+    w1 = (torch.randn((Cout, Cin, 1, 1), generator=g) / Cin ** 0.5).numpy()
+    first = det.conv_bn_silu(xd, w1, b, 1, 1, True, rd)
+    for _ in range(20):
+        assert torch.equal(first, det.conv_bn_silu(xd, w1, b, 1, 1, True, rd))
+
+
 @pytest.mark.parametrize("seed", list(range(24)))
 def test_conv_random_geometry_fp16(seed, monkeypatch):
     """Seeded random layer geometries around the dispatch boundaries of launch_conv (channel counts that are / are not
