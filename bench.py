@@ -36,7 +36,7 @@ WORKLOADS = {
     # name: mosaic edge, seed, tile, step, imgsz, algorithmic conv FLOPs per full tile (yolov8l nc=5)
     "s16k": dict(size=16384, seed=20260104, tile=512, step=0.8, imgsz=512, flop=105.488e9, batch=256,
                  metric="512x512 tiles/sec over 16k x 16k FITS", pre="zscale+minmax"),
-    "c5": dict(size=16384, seed=20260105, tile=640, step=0.8, imgsz=640, flop=164.825e9, batch=128,
+    "c5": dict(size=16384, seed=20260105, tile=640, step=0.8, imgsz=640, flop=164.825e9, batch=256,
                metric="640x640 chan3 tiles/sec over 16k x 16k FITS (config 5 at one-GPU size)", pre="chan3+minmax"),
 }
 

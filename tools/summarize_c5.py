@@ -25,8 +25,13 @@ with open(os.path.join(P, tag + "_c5_summary.md"), "w") as fp:
         t = float(r["TotalDurationNs"])
         fp.write("| `%s` | %s | %.2f | %.1f | %.2f |\n" % (short(r["Name"]), r["Calls"], t / 1e6, t / 1e3 / int(r["Calls"]), 100 * t / tot))
     fp.write("\n## forward kernels as bench.py timed them (hipEvents, every second batch)\n\n")
-    fp.write("Batches of 64..239 tiles run their forward as two concurrent half-batches, so these per-launch times overlap: the\n"
-             "TFLOP/s column understates each kernel's exclusive rate by up to 2x (per-layer exclusive rates: `tools/profile_layers.py 128 640`).\n\n")
+    if 64 <= bench["config"]["tile_batch"] < 240:
+        fp.write("Batches of 64..239 tiles run their forward as two concurrent half-batches, so these per-launch times overlap: the\n"
+                 "TFLOP/s column understates each kernel's exclusive rate by up to 2x (per-layer exclusive rates: `tools/profile_layers.py 128 640`).\n\n")
+    else:
+        r = bench.get("roofline", {})
+        fp.write("Dominant kernel `%s`: %.0f TFLOP/s inside the pipelined pass, %s with the GPU to itself.\n\n" % (
+            r.get("kernel", "?"), r.get("achieved", 0.0), ("%.0f" % r["achieved_exclusive"]) if r.get("achieved_exclusive") else "n/a"))
     fp.write("| kernel | ms total | launches | avg us | TFLOP/s | share |\n|---|---|---|---|---|---|\n")
     for k in sorted(bench.get("forward_kernels", []), key=lambda k: -k["ms_total"]):
         fp.write("| %s | %.2f | %d | %.1f | %.0f | %.3f |\n" % (k["kernel"], k["ms_total"], k["launches"], 1e3 * k["ms_total"] / k["launches"],
