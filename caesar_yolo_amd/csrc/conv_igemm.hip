@@ -2275,6 +2275,180 @@ __global__ __launch_bounds__(512) void stem_down_kernel(const StemDownArgs a) {
     }
 }
 
+// Two-group form of stem_down_kernel (same arithmetic, same outputs): the one-group kernel runs its three parts one after the other
+// on all eight waves -- stem pixels -> LDS 0.66 ms (gather latency + 144 SiLUs per lane), 3x3 s2 from LDS 0.47 ms (MFMAs, weights
+// from L2), epilogue + stores 0.30 ms per 256 tiles -- and its 138 KiB patch leaves no room for a second workgroup.  Here a
+// persistent workgroup (one per CU) has two groups of four waves (waves w and w + 4 share a SIMD), each with its own 72 KiB
+// patch of 8 x 16 output pixels; the patches of the workgroup alternate between the groups, and in every phase one group fills
+// its patch (VALU / memory latency) while the other convolves and stores its previous one (matrix cores): one barrier per phase.
+constexpr int S2_TH = 8, S2_TW = 16, S2_PH = 2 * S2_TH + 1, S2_PW = 2 * S2_TW + 1, S2_EVEN = S2_TW + 1;
+constexpr int S2_ROWS = S2_PH * S2_PW, S2_FRAGS = (S2_ROWS + 15) / 16, S2_BUF = S2_FRAGS * 16 * 128, S2_LDS = 2 * S2_BUF;
+static_assert(S2_FRAGS % 4 == 0, "fragments split evenly over the four waves of a group");
+
+__global__ __launch_bounds__(512) void stem_down2_kernel(const StemDownArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, w4 = wave & 3, wn = w4 & 1, wm = w4 >> 1;
+    char* const buf = smem + grp * S2_BUF;                   // this group's patch
+    const int tiles_x = (a.Wo + S2_TW - 1) / S2_TW, tiles_y = (a.Ho + S2_TH - 1) / S2_TH;
+    const int npatch = a.B * tiles_y * tiles_x;
+    const int NP = (int)blockIdx.x < npatch ? (npatch - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;     // patches of this workgroup
+    const auto rsi = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, a.in_bytes, 0x00020000);
+    const auto rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wgt32), 0, a.wgt32_bytes, 0x00020000);
+
+    // weight fragments of step (tap, h) of the 3x3 s2 conv: rows wn*64 + ni*16 + fr of chunk h, bytes fq*16..
+    constexpr int RING = 4;
+    f16x8 wa[RING][4];
+    const unsigned wl = (unsigned)((wn * 64 + fr) * 64 + fq * 16);
+    auto load_wa = [&](f16x8* dst, int step) {
+        const int h = step & 1, tap = step >> 1;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) dst[ni] = __builtin_bit_cast(f16x8, load_b128(rsw, wl + ni * 1024, (h * 9 + tap) * 8192));
+    };
+    const f16* wp = reinterpret_cast<const f16*>(a.wpk2);
+    const int t0 = 2 * fq, t1 = 2 * fq + 1;                  // the two taps of this lane's k-chunk; tap 8 rides in the second MFMA (fq = 0)
+    const int dh0 = t0 / 3 - 1, dw0 = t0 % 3 - 1, dh1 = t1 / 3 - 1, dw1 = t1 % 3 - 1;
+    const int d0 = (dh0 * a.Wi + dw0) * 8, d1 = (dh1 * a.Wi + dw1) * 8, d2 = (a.Wi + 1) * 8;
+
+    auto coords = [&](int n, int& b, int& oy0, int& ox0) {
+        int id = (int)blockIdx.x + n * (int)gridDim.x;
+        const int tx = id % tiles_x; id /= tiles_x;
+        oy0 = (id % tiles_y) * S2_TH; ox0 = tx * S2_TW; b = id / tiles_y;
+    };
+
+    // ---- fill: the 17 x 33 stem pixels under patch n -> this group's LDS patch (bias + SiLU applied, fp16, zeros outside the map)
+    auto fill = [&](int n) {
+        int b, oy0, ox0;
+        coords(n, b, oy0, ox0);
+        const int sy0 = 2 * oy0 - 1, sx0 = 2 * ox0 - 1;      // stem-map coordinates of LDS pixel (0, 0)
+        // stem panel and bias: re-read per patch (L2 hits, beside the gathers) rather than 48 registers held across the convolution
+        f16x8 sw0[4], sw1[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            sw0[ni] = *reinterpret_cast<const f16x8*>(wp + (ni * 16 + fr) * 64 + fq * 8);
+            sw1[ni] = *reinterpret_cast<const f16x8*>(wp + (ni * 16 + fr) * 64 + 32 + fq * 8);
+        }
+        float bv0[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) bv0[j] = a.bias0[fq * 16 + j];
+        constexpr int NG = S2_FRAGS / 4;
+        u32x2 q0[NG], q1[NG], q2[NG];
+        unsigned inmask = 0;
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            const int g = gi * 4 + w4, p = g * 16 + fr;
+            const int sy = p / S2_PW, q = p - sy * S2_PW;
+            const int sx = q < S2_EVEN ? 2 * q : 2 * (q - S2_EVEN) + 1;
+            const int Y = sy0 + sy, X = sx0 + sx;
+            const bool inmap = p < S2_ROWS && (unsigned)Y < (unsigned)a.H1 && (unsigned)X < (unsigned)a.W1;
+            inmask |= inmap ? (1u << gi) : 0u;
+            const int hc = 2 * Y, wc = 2 * X;
+            const int base = ((b * a.Hi + hc) * a.Wi + wc) * 8;
+            const bool ok0 = inmap && ((hc + dh0) | (wc + dw0)) >= 0, ok1 = inmap && ((hc + dh1) | (wc + dw1)) >= 0;
+            q0[gi] = load_b64(rsi, ok0 ? (unsigned)(base + d0) : CY_OOB);
+            q1[gi] = load_b64(rsi, ok1 ? (unsigned)(base + d1) : CY_OOB);
+            q2[gi] = load_b64(rsi, (inmap && fq == 0) ? (unsigned)(base + d2) : CY_OOB);
+        }
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            const int g = gi * 4 + w4, p = g * 16 + fr;
+            const bool inmap = (inmask >> gi) & 1u;
+            // the fourth NHWC channel is padding: its weights are zero, and masking it keeps a stray NaN out of the sum
+            const u32x4 u0 = {q0[gi].x, q0[gi].y & 0xFFFFu, q1[gi].x, q1[gi].y & 0xFFFFu};
+            const u32x4 u1 = {q2[gi].x, q2[gi].y & 0xFFFFu, 0u, 0u};
+            const f16x8 x0 = __builtin_bit_cast(f16x8, u0), x1 = __builtin_bit_cast(f16x8, u1);
+            f32x4 acc[4];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sw0[ni], x0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(sw1[ni], x1, acc[ni], 0, 0, 0);
+            }
+            f16x8 o0, o1;
+            float v16[16];
+            bias_act16(acc[0], acc[1], acc[2], acc[3], bv0, true, v16);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { o0[j] = (f16)v16[j]; o1[j] = (f16)v16[8 + j]; }
+            const unsigned keep = inmap ? 0xFFFFFFFFu : 0u;
+            const u32x4 k4 = {keep, keep, keep, keep};
+            char* row = buf + p * 128;
+            *reinterpret_cast<u32x4*>(row + (((2 * fq) ^ (p & 7)) << 4)) = __builtin_bit_cast(u32x4, o0) & k4;
+            *reinterpret_cast<u32x4*>(row + (((2 * fq + 1) ^ (p & 7)) << 4)) = __builtin_bit_cast(u32x4, o1) & k4;
+        }
+        // the first weight fragments of the convolution that follows the barrier: in flight across it
+#pragma unroll
+        for (int st = 0; st < RING - 1; ++st) load_wa(wa[st], st);
+    };
+
+    // ---- convolve + store: 3x3 stride 2 over this group's patch (wave: 4 output rows x 16 columns x 64 channels)
+    auto conv_store = [&](int n) {
+        int b, oy0, ox0;
+        coords(n, b, oy0, ox0);
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[ni][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int pl = wm * 8 * S2_PW + fr;                   // LDS row of (first output row of this wave, tap (0,0), column fr)
+#pragma unroll
+        for (int step = 0; step < 18; ++step) {
+            const int tap = step >> 1, h = step & 1, kh = tap / 3, kw = tap % 3;
+            if (step + RING - 1 < 18) load_wa(wa[(step + RING - 1) % RING], step + RING - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            f16x8 xb[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int cm = (2 * m + kh) * S2_PW + (kw == 1 ? S2_EVEN : (kw == 2 ? 1 : 0));
+                const int p = pl + cm;
+                xb[m] = *reinterpret_cast<const f16x8*>(buf + p * 128 + (((h * 4 + fq) ^ (p & 7)) << 4));
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    acc[ni][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[step % RING][ni], xb[m], acc[ni][m], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const int cbase = wn * 64 + fq * 16;
+        float bv[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) bv[j] = a.bias1[cbase + j];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int oy = oy0 + wm * 4 + m, ox = ox0 + fr;
+            if (oy >= a.Ho || ox >= a.Wo) continue;
+            const long pix = ((long)b * a.Ho + oy) * a.Wo + ox;
+            f16x8 o0, o1;
+            float v16[16];
+            bias_act16(acc[0][m], acc[1][m], acc[2][m], acc[3][m], bv, true, v16);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { o0[j] = (f16)v16[j]; o1[j] = (f16)v16[8 + j]; }
+            f16* dst = reinterpret_cast<f16*>(a.out) + pix * a.out_ct + a.out_coff + cbase;
+            *reinterpret_cast<f16x8*>(dst) = o0;
+            *reinterpret_cast<f16x8*>(dst + 8) = o1;
+        }
+    };
+
+    // Patch n of the workgroup belongs to group n & 1; phase n: its group fills it, phase n + 1: the same group convolves it, so in
+    // every phase one group fills and the other convolves.  Phases 0 .. NP, one barrier each; every wave executes NP + 1 of them
+    // (group 1 sits out phase 0; the group that does not own the last patch sits out the last phase).  One straight-line loop
+    // body for both groups: with a per-phase branch on the role the two instruction streams cost 388 B of scratch.
+    auto phase_barrier = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if (grp) phase_barrier();
+#pragma unroll 1
+    for (int n = grp; n < NP; n += 2) {
+        fill(n);
+        phase_barrier();
+        conv_store(n);
+        phase_barrier();
+    }
+    if (((NP + grp) & 1) == 0) phase_barrier();
+}
+
 long stem_down_blocks(const StemDownArgs& a) {
     return (long)a.B * ((a.Ho + SD_TH - 1) / SD_TH) * ((a.Wo + SD_TW - 1) / SD_TW);
 }
@@ -2287,6 +2461,17 @@ hipError_t launch_stem_down(const StemDownArgs& a, hipStream_t s) {
         attr_set = true;
     }
     StemDownArgs b2 = a; b2.dbg = dev_knob("CY_SD_DBG", 0);
+    // the two-group persistent form once every workgroup gets at least two patches (both wave groups busy), else the one-group
+    // form; their outputs are bit for bit the same, so the choice may depend on the launch size.  CY_STEM_V = 1 / 2 forces one
+    // (read per call: tests).  256 tiles of 512^2: 1.44-1.47 -> 1.18-1.20 ms alone, 2.38 -> 1.58 ms inside the pipelined pass.
+    const int v = env_knob("CY_STEM_V", 0);
+    const long np = (long)a.B * ((a.Ho + S2_TH - 1) / S2_TH) * ((a.Wo + S2_TW - 1) / S2_TW);
+    if (v == 2 || (v == 0 && np >= 512)) {
+        static bool set2 = false;
+        if (!set2) { hipFuncSetAttribute(reinterpret_cast<const void*>(stem_down2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, S2_LDS); set2 = true; }
+        hipLaunchKernelGGL(stem_down2_kernel, dim3((unsigned)(np < 256 ? np : 256)), dim3(512), S2_LDS, s, b2);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(stem_down_kernel, dim3((unsigned)stem_down_blocks(a)), dim3(512), SD_LDS, s, b2);
     return hipGetLastError();
 }

@@ -147,3 +147,22 @@ def test_batch_invariant_mode_is_bit_exact(monkeypatch):
         assert torch.equal(p1[0], p4[i]), "tile %d differs between batch 1 and batch 4" % i
     p3 = det.forward(xin[1:4].contiguous()).cpu()
     assert torch.equal(p3, p4[1:4])
+
+
+@pytest.mark.parametrize("shape", [(3, 160, 192), (20, 256, 256), (1, 512, 512), (5, 96, 416)])
+def test_two_group_stem_kernel_is_bit_identical(shape, monkeypatch):
+    """The persistent two-group form of the fused stem + first down conv (CY_STEM_V=2: 8 x 16 output patches, one wave group
+    fills its LDS patch while the other convolves its previous one) does the same arithmetic in the same order as the
+    one-group kernel: the whole head output must be bit for bit the same, on ragged maps and on more patches than workgroups."""
+    B, H, W = shape
+    det = detector("fp16", max_batch=20, max_imgsz=512)
+    g = torch.Generator().manual_seed(B * 1000 + H + W)
+    x = torch.rand((B, H, W, 4), generator=g).half().cuda()
+    monkeypatch.setenv("CY_STEM_FUSE", "2")
+    monkeypatch.setenv("CY_STEM_V", "1")
+    ref = det.forward(x).clone()
+    monkeypatch.setenv("CY_STEM_V", "2")
+    for _ in range(3):
+        got = det.forward(x)
+        torch.cuda.synchronize()
+        assert torch.equal(ref, got)
