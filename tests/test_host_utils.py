@@ -193,3 +193,34 @@ def test_rank_regions_of_the_16k_mosaic_are_an_eighth_plus_halo():
             g = [grid[t] for t in tids]
             px += (max(t[1] for t in g) - min(t[0] for t in g)) * (max(t[3] for t in g) - min(t[2] for t in g))
         assert px <= 0.18 * n * n
+
+
+def test_mosaic_source_widens_nearly_full_width_bands_to_whole_file_rows(tmp_path):
+    """Host logic of the ingest path (no GPU): a band that covers >= 90 % of the image width of a memory-mapped FITS payload is
+    widened to whole rows and handed to the upload together with (file, byte offset of its first row) for the pread() path;
+    a narrower region stays a view of the map with no file hint; the returned origin is the region's, for rebasing tiles."""
+    import numpy as np
+    from caesar_yolo_amd import utils
+    from caesar_yolo_amd.inference import MosaicSource
+    img = np.arange(200 * 320, dtype=np.float32).reshape(200, 320)
+    path = str(tmp_path / "w.fits")
+    utils.write_fits_image(path, img, {})
+    data, _ = utils.read_fits_image(path)
+    assert isinstance(data, np.memmap)
+    calls = []
+
+    class FakeDet(object):
+        def mosaic_to_device(self, arr, big_endian=None, file_rows=None):
+            calls.append((arr.shape, file_rows, bool(big_endian)))
+            return np.asarray(arr).astype("<f4")
+
+    src = MosaicSource(data)
+    t, ox, oy = src.region(FakeDet(), 0, 300, 10, 150)          # 300 of 320 columns
+    assert (ox, oy) == (0, 10) and t.shape == (140, 320)
+    shape, file_rows, be = calls[-1]
+    assert shape == (140, 320) and be and file_rows == (path, int(data.offset) + 10 * 320 * 4)
+    assert np.array_equal(t, img[10:150])
+    t2, ox2, oy2 = src.region(FakeDet(), 200, 320, 0, 200)       # 120 of 320 columns: a plain view, own origin
+    assert (ox2, oy2) == (200, 0) and calls[-1][0] == (200, 120) and calls[-1][1] is None
+    assert np.array_equal(t2, img[:, 200:320])
+    assert src.bytes_uploaded == (140 * 320 + 200 * 120) * 4
