@@ -408,7 +408,8 @@ class SFinder(object):
         det = self.model.engine(self._device())
         if not resident:
             return det, MosaicSource(data, big_endian=True)
-        return det, det.mosaic_to_device(data, big_endian=True)
+        src = MosaicSource(data, big_endian=True)          # whole image = one full-width band: the pread() upload path
+        return det, src.region(det, 0, self.nx, 0, self.ny)[0]
 
     def _beam_info(self):
         """Beam / pixel metadata of the reference's read_img (caesar_yolo/inference.py:430-468): beamArea = pi*BMAJ*BMIN /
