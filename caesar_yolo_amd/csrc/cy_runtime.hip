@@ -29,6 +29,7 @@ struct cy_ctx {
     char* ws = nullptr; size_t ws_bytes = 0;           // activations
     // second workspace + stream: cy_detect_tiles runs batches of 64..239 tiles as two concurrent half-batches (forward_split)
     char* ws2 = nullptr; size_t ws2_bytes = 0; hipStream_t s_fwd2 = nullptr; hipEvent_t ev_split[2] = {nullptr, nullptr};
+    char* ws3 = nullptr; size_t ws3_bytes = 0; hipStream_t s_small = nullptr;     // small-batch lane: its own workspace and (lowest-priority) stream
     std::vector<size_t> toff; std::vector<size_t> tbytes;   // per tensor, for the last forward geometry
     int lastB = 0, lastH = 0, lastW = 0;
     // stage buffers (sized at load for max_batch), two sets: cy_detect_tiles software-pipelines consecutive batches
@@ -90,6 +91,9 @@ void free_all(cy_ctx* c) {
     if (c->ws2) hipFree(c->ws2);
     c->ws2 = nullptr; c->ws2_bytes = 0;
     if (c->s_fwd2) { hipStreamDestroy(c->s_fwd2); c->s_fwd2 = nullptr; }
+    if (c->ws3) hipFree(c->ws3);
+    c->ws3 = nullptr; c->ws3_bytes = 0;
+    if (c->s_small) { hipStreamDestroy(c->s_small); c->s_small = nullptr; }
     for (auto& e : c->ev_split) if (e) { hipEventDestroy(e); e = nullptr; }
     for (auto& b : c->sb) {
         void* ptrs[] = {b.netin, b.pred, b.cand, b.cand_anchor, b.cand_count, b.keys, b.det, b.det_anchor, b.det_count,
@@ -502,6 +506,20 @@ static int ensure_second_workspace(cy_ctx* c) {
     HIPCHK(c, hipMalloc(&c->ws2, c->ws2_bytes));
     HIPCHK(c, hipStreamCreateWithFlags(&c->s_fwd2, hipStreamNonBlocking));
     for (auto& ev : c->ev_split) HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    return CY_OK;
+}
+// The small-batch lane (cy_detect_tiles): batches of fewer than 64 tiles run their forward on a stream of the LOWEST priority
+// with a workspace of their own, so that their ~105 launches of a few workgroups each take what the full batch beside them
+// leaves free instead of competing with it.
+static int ensure_small_lane(cy_ctx* c) {
+    if (c->ws3) return CY_OK;
+    c->ws3_bytes = c->ws_bytes / 4 + (1u << 20);            // 63 of at least 64 x 4 tiles... sized for < 64 tiles of a context built for >= 64
+    if (c->cfg.max_batch < 256) c->ws3_bytes = c->ws_bytes;
+    HIPCHK(c, hipMalloc(&c->ws3, c->ws3_bytes));
+    int prio_lo = 0, prio_hi = 0;
+    hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    static const int low = env_knob("CY_SMALL_PRIO", 1);
+    HIPCHK(c, hipStreamCreateWithPriority(&c->s_small, hipStreamNonBlocking, low ? prio_lo : 0));
     return CY_OK;
 }
 static int dual_mode() { const char* e = getenv("CY_DUAL_FORWARD"); return e ? atoi(e) : 1; }
@@ -1016,10 +1034,10 @@ int cy_detect_tiles(cy_ctx* c, const float* d_mosaic, int MH, int MW, const int*
     static const int small_lane = env_knob("CY_SMALL_LANE", 1);
     const bool small = small_lane && c->prec == PREC_F16 && B < 64 && c->cfg.max_batch >= 64;    // (contexts sized for tile batches only)
     int rc = CY_OK;
-    if (small) { rc = ensure_second_workspace(c); if (rc) return rc; }
+    if (small) { rc = ensure_small_lane(c); if (rc) return rc; }
     const int sl = small ? 2 : (int)(c->batches & 1);
     const bool reuse = small ? c->small_batches >= 1 : c->batches >= 2;
-    hipStream_t sf = small ? c->s_fwd2 : sm;
+    hipStream_t sf = small ? c->s_small : sm;
     c->slot = sl;
     // order the side streams after whatever the caller already queued on `stream` -- only where that matters: the first batch
     // after load / flush, or after cy_mosaic_prepare.  Later batches are ordered by ev_fwd / ev_post alone, so that the
@@ -1037,7 +1055,7 @@ int cy_detect_tiles(cy_ctx* c, const float* d_mosaic, int MH, int MW, const int*
     if (reuse) HIPCHK(c, hipStreamWaitEvent(sf, c->ev_post[sl], 0));
     if (small) {
         c->split_last = false;
-        rc = forward_on(c, c->S().netin, B, lb.H, lb.W, c->S().pred, sf, c->ws2, c->ws2_bytes, false);
+        rc = forward_on(c, c->S().netin, B, lb.H, lb.W, c->S().pred, sf, c->ws3, c->ws3_bytes, false);
     } else {
         rc = forward_split(c, c->S().netin, B, lb.H, lb.W, c->S().pred, sm);
     }
