@@ -55,6 +55,7 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-launch hipEvents in the timed region")
+    ap.add_argument("--no-exclusive", action="store_true", help="skip the extra forward passes after the timed region that time the dominant kernel alone (roofline.achieved_exclusive)")
     ap.add_argument("--dry-run", action="store_true",
                     help="ranks only rendezvous, partition the grid and run the (empty) all-gather on CPU tensors: exercises the "
                          "launch path on a box without GPUs (tests/test_bench_spawn.py)")
@@ -306,13 +307,13 @@ def run_rank(args):
         step()
     for k in tsplit:
         tsplit[k] = 0.0
-    if not args.no_profile:
-        det.profile(2)                   # hipEvents around every launch of every second batch (all of them cost ~3 % of the step)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.time()
-    for _ in range(args.steps):
+    for k in range(args.steps):
+        if k == args.steps - 1 and not args.no_profile:
+            det.profile(1)               # hipEvents around EVERY launch of the last timed step (all batches, both lanes): ~3 % of that step
         cat, stats = step()
     torch.cuda.synchronize()
     if world > 1:
@@ -329,12 +330,15 @@ def run_rank(args):
         allr = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank = [[float(v) for v in t.cpu()] for t in allr]
-    prof = det.profile_summary() if not args.no_profile else None
+    # main lane (the full batches on the launch stream: 95 % of the tiles) and all launches incl. the small-batch lane, whose
+    # kernels run on their own stream BESIDE the main lane's (their event times and the main lane's overlap)
+    prof = det.profile_summary(0) if not args.no_profile else None
+    prof_all = {p["kernel"]: p for p in det.profile_summary(-1) if p["launches"]} if not args.no_profile else None
     det.profile(False)
     # beside the in-situ figure: the same kernels timed with the GPU to themselves (one full batch through cy_forward on the
     # launch stream, no preprocessing / post-processing / second batch beside it), after the timed region
     prof_excl = None
-    if prof and world == 1:
+    if prof and world == 1 and not args.no_exclusive:
         lbx = utils_letterbox(wl["tile"], wl["tile"], wl["imgsz"])
         x = torch.rand((batch, lbx.H, lbx.W, 4), device="cuda").to(det.dtype)
         det.forward(x)
@@ -390,6 +394,9 @@ def run_rank(args):
                                    "unit": "TFLOP/s", "frac": ach / PEAK_FP16_DENSE_TFLOPS, "traffic": traffic,
                                    "traffic_source": ("%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command line, "
                                                       "2 x FETCH + WRITE; not measured in this run)" % tsrc) if tsrc else None,
+                                   "achieved_all_launches": ((prof_all[k["kernel"]]["flops"] / (prof_all[k["kernel"]]["ms"] * 1e-3) / 1e12)
+                                                             if prof_all and k["kernel"] in prof_all and prof_all[k["kernel"]]["ms"] > 0 else None),
+                                   "launches_all": (prof_all[k["kernel"]]["launches"] if prof_all and k["kernel"] in prof_all else None),
                                    "achieved_exclusive": ((prof_excl[k["kernel"]]["flops"] / (prof_excl[k["kernel"]]["ms"] * 1e-3) / 1e12)
                                                           if prof_excl and k["kernel"] in prof_excl and prof_excl[k["kernel"]]["ms"] > 0 else None),
                                    "achieved_exclusive_note": "same kernel, all its launches of one full batch through the forward pass alone on the GPU "
@@ -397,7 +404,7 @@ def run_rank(args):
                                                               "streams and the small-batch lane)",
                                    "flops_per_launch": k["flops"] / k["launches"],
                                    "avg_launch_ms": k["ms"] / k["launches"], "launches": k["launches"],
-                                   "timing": "hipEvents around every launch of every second batch on the launch stream, over the timed region (rank 0)"
+                                   "timing": "hipEvents around every launch of the forward pass during the last timed step (rank 0), each on the stream it runs on.  `achieved`: the launches of the full batches (main lane, 95 % of the tiles); `achieved_all_launches`: those plus the launches of the small-batch lane, which run on another stream beside them (the two sets of event times overlap, so their sum exceeds the step)"
                                              + ("; batches of 64..239 tiles run their forward as two concurrent half-batches on two streams, so the "
                                                 "launches timed here overlap each other and `achieved` understates the kernel's exclusive rate by up to 2x"
                                                 if 64 <= batch < 240 else "")}
@@ -405,8 +412,8 @@ def run_rank(args):
             out["forward_kernels"] = [{"kernel": p["kernel"], "ms_total": p["ms"], "launches": p["launches"],
                                        "TFLOP/s": (p["flops"] / (p["ms"] * 1e-3) / 1e12) if p["ms"] > 0 else 0.0,
                                        "share_of_forward": p["ms"] / tot_ms if tot_ms else 0.0} for p in prof]
-            out["profiled_forward_share_of_step"] = tot_ms / (1000.0 * dt) if dt > 0 else None   # only every 2nd batch is timed
-            out["profile_stride_batches"] = 2
+            out["profiled_forward_share_of_step"] = tot_ms / ms_step if ms_step > 0 else None   # > 1 is possible: the small-batch lane runs beside the main lane
+            out["profiled_steps"] = 1
         if world == 1 and not args.no_cpu_baseline:
             scale, names, wd, _ = W.read_cyw(model._wpath)
             out["cpu_baseline"] = cpu_baseline(mosaic_host, grid, (scale, names, wd), wl)

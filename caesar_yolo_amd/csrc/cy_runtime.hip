@@ -57,7 +57,7 @@ struct cy_ctx {
     bool bneck_fused_last = false;                       // ... and 64-channel bottlenecks as one kernel each (their cv1 outputs do not exist)
     int prof_stride = 1; unsigned long fwd_calls = 0;   // profiling on: every prof_stride-th cy_forward call is timed
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
-    struct ProfRec { size_t e0, e1; int kind; double flops; int conv; };
+    struct ProfRec { size_t e0, e1; int kind; double flops; int conv; int lane; };    // lane: 0 main stream(s), 1 small-batch lane
     std::vector<ProfRec> prof;
 };
 
@@ -567,7 +567,7 @@ static int forward_on(cy_ctx* c, const void* d_netin, int B, int H, int W, float
     auto prof_done = [&](int kind, double flops) {
         if (!prof_now) return;
         const size_t e = stamp();
-        c->prof.push_back({ev_prev, e, kind, flops, cur_conv});
+        c->prof.push_back({ev_prev, e, kind, flops, cur_conv, (c->ws3 && ws == c->ws3) ? 1 : 0});
         ev_prev = e;
     };
     // Optional (CY_SUB=n): run the full-resolution head of the graph (stem .. model.2, levels 1-2; tensors of 134-537 MB
@@ -745,7 +745,11 @@ int cy_profile_enable(cy_ctx* c, int on) {
     return CY_OK;
 }
 
-int cy_profile_summary(cy_ctx* c, cy_prof_entry* out, int cap) {
+static int profile_summary_lane(cy_ctx* c, cy_prof_entry* out, int cap, int lane);
+int cy_profile_summary(cy_ctx* c, cy_prof_entry* out, int cap) { return profile_summary_lane(c, out, cap, -1); }
+int cy_profile_summary_lane(cy_ctx* c, cy_prof_entry* out, int cap, int lane) { return profile_summary_lane(c, out, cap, lane); }
+
+static int profile_summary_lane(cy_ctx* c, cy_prof_entry* out, int cap, int lane) {
     // one entry per forward kernel variant (conv variants in ConvVariant order, then stem, pool)
     const int n = CONV_NUM_VARIANTS + 5;
     if (!c || !out || cap < n) return fail(c, CY_ERR_ARG, "bad arguments");
@@ -758,6 +762,7 @@ int cy_profile_summary(cy_ctx* c, cy_prof_entry* out, int cap) {
         strncpy(out[k].kernel, nm, sizeof(out[k].kernel) - 1);
     }
     for (const auto& r : c->prof) {
+        if (lane >= 0 && r.lane != lane) continue;
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, c->ev_pool[r.e0], c->ev_pool[r.e1]) != hipSuccess) continue;
         out[r.kind].ms += ms; out[r.kind].flops += r.flops; out[r.kind].launches += 1;
@@ -1055,7 +1060,7 @@ int cy_detect_tiles(cy_ctx* c, const float* d_mosaic, int MH, int MW, const int*
     if (reuse) HIPCHK(c, hipStreamWaitEvent(sf, c->ev_post[sl], 0));
     if (small) {
         c->split_last = false;
-        rc = forward_on(c, c->S().netin, B, lb.H, lb.W, c->S().pred, sf, c->ws3, c->ws3_bytes, false);
+        rc = forward_on(c, c->S().netin, B, lb.H, lb.W, c->S().pred, sf, c->ws3, c->ws3_bytes, true);      // (profiled like the main lane)
     } else {
         rc = forward_split(c, c->S().netin, B, lb.H, lb.W, c->S().pred, sm);
     }

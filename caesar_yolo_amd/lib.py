@@ -16,7 +16,7 @@ F16, F32 = 0, 1
 EXPORTS = [
     "cy_create", "cy_destroy", "cy_last_error", "cy_load_weights", "cy_load_weights_mem", "cy_num_classes",
     "cy_class_name", "cy_plan_num_convs", "cy_plan_conv_desc", "cy_letterbox_geometry", "cy_num_anchors",
-    "cy_pred_elems", "cy_profile_enable", "cy_profile_summary", "cy_profile_layers", "cy_mosaic_prepare", "cy_letterbox_pack", "cy_preproc", "cy_preproc_planes", "cy_preproc_params", "cy_forward", "cy_debug_read_conv",
+    "cy_pred_elems", "cy_profile_enable", "cy_profile_summary", "cy_profile_summary_lane", "cy_profile_layers", "cy_mosaic_prepare", "cy_letterbox_pack", "cy_preproc", "cy_preproc_planes", "cy_preproc_params", "cy_forward", "cy_debug_read_conv",
     "cy_decode_nms", "cy_debug_stamps", "cy_debug_cand_counts", "cy_iou_merge", "cy_detect_tiles", "cy_detect_flush", "cy_detect_counters", "cy_conv_bn_silu", "cy_bottleneck64", "cy_make_tile_records",
     "cy_merge_edge_sources",
 ]
@@ -95,6 +95,7 @@ def load():
         "cy_forward": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
         "cy_profile_enable": (C.c_int, [vp, C.c_int]),
         "cy_profile_summary": (C.c_int, [vp, C.POINTER(cy_prof_entry), C.c_int]),
+        "cy_profile_summary_lane": (C.c_int, [vp, C.POINTER(cy_prof_entry), C.c_int, C.c_int]),
         "cy_profile_layers": (C.c_int, [vp, C.POINTER(cy_prof_entry), C.c_int]),
         "cy_debug_read_conv": (C.c_int, [vp, C.c_char_p, fp, C.c_size_t, ip]),
         "cy_decode_nms": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,

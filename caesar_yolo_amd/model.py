@@ -201,9 +201,10 @@ class HipDetector(object):
     def profile(self, on):
         self._chk(self.lib.cy_profile_enable(self.ctx, int(on)))            # True/1: every forward call; N > 1: every N-th
 
-    def profile_summary(self):
+    def profile_summary(self, lane=-1):
+        """lane: -1 all launches, 0 the main lane of detect_tiles (full batches), 1 its small-batch lane."""
         ent = (L.cy_prof_entry * 32)()
-        n = self._chk(self.lib.cy_profile_summary(self.ctx, ent, 32))
+        n = self._chk(self.lib.cy_profile_summary_lane(self.ctx, ent, 32, int(lane)))
         return [dict(kernel=ent[i].kernel.decode(), ms=ent[i].ms, flops=ent[i].flops, launches=ent[i].launches) for i in range(n)]
 
     def profile_layers(self):

@@ -108,6 +108,9 @@ int cy_forward(cy_ctx* ctx, const void* d_netin, int B, int H, int W, float* d_p
 typedef struct cy_prof_entry { char kernel[64]; double ms; double flops; long launches; } cy_prof_entry;
 int cy_profile_enable(cy_ctx* ctx, int on);    /* 0 off, 1 every cy_forward call, N > 1 every N-th call (sampling) */
 int cy_profile_summary(cy_ctx* ctx, cy_prof_entry* out, int cap);
+/* the same for the launches of one lane of cy_detect_tiles only: 0 = the caller's stream (full batches, incl. the second stream of
+ * a split batch), 1 = the small-batch lane, -1 = all */
+int cy_profile_summary_lane(cy_ctx* ctx, cy_prof_entry* out, int cap, int lane);
 int cy_profile_layers(cy_ctx* ctx, cy_prof_entry* out, int cap);    /* the same, one entry per convolution (graph order) */
 /* copy the output of one named convolution of the last cy_forward to host as fp32 [B][C][Ho][Wo] (test hook) */
 int cy_debug_read_conv(cy_ctx* ctx, const char* conv_name, float* h_out, size_t cap_elems, int* dims4);

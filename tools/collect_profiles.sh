@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 python3 $R/bench.py --config $CFG > $R/gpurun_out/${TAG}_bench.json 2> $R/gpurun_out/${TAG}_bench.err
 echo "bench done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_ktrace -- python3 $R/bench.py --config $CFG --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_ktrace -- python3 $R/bench.py --config $CFG --steps 1 --warmup 1 --no-cpu-baseline --no-exclusive > $R/gpurun_out/${TAG}_bench_under_rocprof.json 2>/dev/null
 echo "kernel trace done"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_pmc_fetch -- python3 $R/bench.py --config $CFG --steps 1 --warmup 0 --no-cpu-baseline --no-profile > /dev/null 2>&1
 echo "pmc fetch done"

@@ -24,7 +24,7 @@ with open(os.path.join(P, tag + "_c5_summary.md"), "w") as fp:
     for r in rows[:16]:
         t = float(r["TotalDurationNs"])
         fp.write("| `%s` | %s | %.2f | %.1f | %.2f |\n" % (short(r["Name"]), r["Calls"], t / 1e6, t / 1e3 / int(r["Calls"]), 100 * t / tot))
-    fp.write("\n## forward kernels as bench.py timed them (hipEvents, every second batch)\n\n")
+    fp.write("\n## forward kernels as bench.py timed them (hipEvents around every main-lane launch of the last timed step)\n\n")
     if 64 <= bench["config"]["tile_batch"] < 240:
         fp.write("Batches of 64..239 tiles run their forward as two concurrent half-batches, so these per-launch times overlap: the\n"
                  "TFLOP/s column understates each kernel's exclusive rate by up to 2x (per-layer exclusive rates: `tools/profile_layers.py 128 640`).\n\n")
