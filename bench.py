@@ -53,6 +53,7 @@ def parse_args(argv=None):
     ap.add_argument("--config", choices=sorted(WORKLOADS), default="s16k")
     ap.add_argument("--size", type=int, default=0, help="mosaic edge (default: the workload's)")
     ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--precision", default="fp16", help="context precision of the headline run: fp16 | fp16x3 | fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-launch hipEvents in the timed region")
     ap.add_argument("--no-exclusive", action="store_true", help="skip the extra forward passes after the timed region that time the dominant kernel alone (roofline.achieved_exclusive)")
@@ -256,13 +257,13 @@ def run_rank(args):
     mosaic_host = None
     model = None
     if rank == 0:
-        model = YOLO("seeded:l:5", precision="fp16", max_batch=batch, max_imgsz=wl["imgsz"], device=local)
+        model = YOLO("seeded:l:5", precision=args.precision, max_batch=batch, max_imgsz=wl["imgsz"], device=local)
         mosaic_host = synth.make_mosaic(size, seed=wl["seed"])
         utils.write_fits_image(fits_path, mosaic_host, synth.FITS_CARDS)
     if world > 1:
         dist.barrier()
     if model is None:
-        model = YOLO("seeded:l:5", precision="fp16", max_batch=batch, max_imgsz=wl["imgsz"], device=local)
+        model = YOLO("seeded:l:5", precision=args.precision, max_batch=batch, max_imgsz=wl["imgsz"], device=local)
     det = model.engine(local)
     grid = utils.generate_tiles(0, size - 1, 0, size - 1, wl["tile"], wl["tile"], wl["step"], wl["step"])
     cfg = CP.device_pipeline(wl["pre"]).program()
@@ -360,7 +361,7 @@ def run_rank(args):
         out = {
             "metric": wl["metric"], "value": value, "unit": "tiles/s", "n_gpus": n_gpus,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": {"fp16": "f16", "fp32": "f32"}.get(args.precision, args.precision), "data": "synthetic",
             "config": {"workload": "synthetic %dx%d 1-chan FITS (S%s recipe, seed %d), %dx%d tiles step %.1f (%d tiles), %s, "
                                    "yolov8l nc=5 seeded weights, imgsz %d, conf 0.7, iou 0.5, merge 0.3/0.8, per-tile IoU merge + "
                                    "cross-tile merge" % (size, size, "32k" if args.config == "c5" else "16k", wl["seed"], wl["tile"],

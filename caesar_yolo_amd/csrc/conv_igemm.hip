@@ -18,6 +18,7 @@
 // fragment reads are conflict-free (slot = chunk ^ (row & 7): conflict-free for any 16 consecutive rows, whatever the first row -- the 3x3 taps of the
 // halo kernels read at arbitrary row offsets; a 256-byte bank row holds two 128-byte tile rows).
 #include "cy_kernels.h"
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 
@@ -84,6 +85,54 @@ __device__ __forceinline__ void bias_act16(const f32x4& a0, const f32x4& a1, con
     }
 }
 
+// fp16x3 context: the same epilogue with the accumulator first multiplied by the power of two that undoes the weight scale of its
+// output channel, and the result stored as two fp16 halves hi = fp16(v), lo = fp16(v - hi) (lo_off halves behind hi)
+__device__ __forceinline__ void scale_bias_act16(const f32x4& a0, const f32x4& a1, const f32x4& a2, const f32x4& a3, const float (&bv)[16],
+                                                 const float (&sc)[16], bool act, float (&v)[16]) {
+    const f32x4 acc[4] = {a0, a1, a2, a3};
+    if (act) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x2 t = f32x2{acc[ni][2 * h], acc[ni][2 * h + 1]} * f32x2{sc[ni * 4 + 2 * h], sc[ni * 4 + 2 * h + 1]} +
+                          f32x2{bv[ni * 4 + 2 * h], bv[ni * 4 + 2 * h + 1]};
+                f32x2 e = t * f32x2{-1.44269504088896341f, -1.44269504088896341f};
+                e = f32x2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])} + f32x2{1.0f, 1.0f};
+                t = t * f32x2{__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+                v[ni * 4 + 2 * h] = t[0]; v[ni * 4 + 2 * h + 1] = t[1];
+            }
+    } else {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[ni * 4 + j] = acc[ni][j] * sc[ni * 4 + j] + bv[ni * 4 + j];
+    }
+}
+__device__ __forceinline__ void store_split16(f16* dst, int lo_off, const float (&v)[16]) {
+    f16x8 h0, h1, l0, l1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        h0[j] = (f16)v[j]; h1[j] = (f16)v[8 + j];
+        l0[j] = (f16)(v[j] - (float)h0[j]); l1[j] = (f16)(v[8 + j] - (float)h1[j]);
+    }
+    *reinterpret_cast<f16x8*>(dst) = h0;
+    *reinterpret_cast<f16x8*>(dst + 8) = h1;
+    *reinterpret_cast<f16x8*>(dst + lo_off) = l0;
+    *reinterpret_cast<f16x8*>(dst + lo_off + 8) = l1;
+}
+__device__ __forceinline__ void store_split1(f16* dst, int lo_off, float v) {
+    const f16 h = (f16)v;
+    dst[0] = h; dst[lo_off] = (f16)(v - (float)h);
+}
+// virtual K chunk of the fp16x3 passes [x_hi | x_lo | x_hi] -> physical chunk; lo = 1 in the middle pass
+__device__ __forceinline__ int x3_chunk(int v, int per_pass, int& lo) {
+    lo = 0;
+    if (v >= 2 * per_pass) return v - 2 * per_pass;
+    if (v >= per_pass) { lo = 1; return v - per_pass; }
+    return v;
+}
+
 template <typename T> struct Elem;
 template <> struct Elem<f16> { static constexpr int BKE = 64, EPC = 8, ES = 2; };
 template <> struct Elem<float> { static constexpr int BKE = 32, EPC = 4, ES = 4; };
@@ -109,8 +158,9 @@ __device__ __forceinline__ u32x4 load_b128(__amdgpu_buffer_rsrc_t rs, unsigned v
     return __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
 }
 
-template <typename T, int WM, int WN, int MI, int NSTAGE = 2>
+template <typename T, int WM, int WN, int MI, int NSTAGE = 2, bool SPLIT = false>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_igemm_kernel(const ConvArgs a) {
+    static_assert(!SPLIT || sizeof(T) == 2, "fp16x3: fp16 operands");
     constexpr int BM = WM * MI * 16, BN = WN * 64, NT = WM * WN * 64, RPR = NT / 8;
     constexpr int BKE = Elem<T>::BKE, EPC = Elem<T>::EPC, ES = Elem<T>::ES;
     constexpr int AROWS = BM / RPR, BROWS = BN / RPR;        // rows each thread stages per slab (RPR rows per round)
@@ -126,7 +176,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_ige
     const int id = xcd_remap(blockIdx.x, nwg);
     const int m0 = (id / ntn) * BM, n0 = (id % ntn) * BN;
     const int taps = a.k * a.k, cpad = pad128(a.Cout);
-    const int cchunks = (a.Cin + BKE - 1) / BKE;
+    const int pchunks = (a.Cin + BKE - 1) / BKE;             // K chunks of one pass over the input channels
+    const int cchunks = SPLIT ? 3 * pchunks : pchunks;       // fp16x3: three passes (x_hi w_hi, x_lo w_hi, x_hi w_lo)
     const int nslab = taps * cchunks;
 
     const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in0), 0, a.in0_bytes, 0x00020000);
@@ -168,19 +219,22 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_ige
     const int cq = q ^ (r0 & 7);
     typedef __attribute__((address_space(3))) void lds_void;
     auto dma = [&](int stage, int tap, int cc) {
-        const int c = cc * BKE + cq * EPC;
+        int lo = 0;
+        const int ccp = SPLIT ? x3_chunk(cc, pchunks, lo) : cc;       // physical chunk of the input (the weights are packed per virtual chunk)
+        const int lo0 = SPLIT && lo ? a.in0_lo : 0, lo1 = SPLIT && lo ? a.in1_lo : 0;
+        const int c = ccp * BKE + cq * EPC;
         const int kh = tap / a.k, kw = tap - kh * a.k;
         const int dpix = kh * a.Wi + kw;
         const bool cin_ok = c < a.Cin;
-        const bool seg1 = cc * BKE >= a.c0;               // wave-uniform: segment boundaries are multiples of BKE
+        const bool seg1 = ccp * BKE >= a.c0;              // wave-uniform: segment boundaries are multiples of BKE
         char* A = smem + stage * STAGE + wave_u * (8 * 128);
         char* Bm = A + A_BYTES;
 #pragma unroll
         for (int i = 0; i < AROWS; ++i) {
             const bool ok = cin_ok && ((vmask[i] >> tap) & 1u);
             unsigned off;
-            if (!seg1) off = (unsigned)((pix0[i] + (a.up0 ? 0 : dpix)) * a.in0_ct + a.in0_coff + c) * ES;
-            else       off = (unsigned)((pix1[i] + dpix) * a.in1_ct + a.in1_coff + (c - a.c0)) * ES;
+            if (!seg1) off = (unsigned)((pix0[i] + (a.up0 ? 0 : dpix)) * a.in0_ct + a.in0_coff + lo0 + c) * ES;
+            else       off = (unsigned)((pix1[i] + dpix) * a.in1_ct + a.in1_coff + lo1 + (c - a.c0)) * ES;
             off = ok ? off : CY_OOB;
             lds_void* dst = (lds_void*)(A + i * (RPR * 128));
             if (seg1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, dst, 16, off, 0, 0, 0);
@@ -295,6 +349,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_ige
     float bv[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) bv[j] = a.bias[cbase + j];       // bias is padded to Cout_pad64
+    float sc[SPLIT ? 16 : 1];
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sc[j] = a.oscale[cbase + j];
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int m = m0 + wm * (MI * 16) + mi * 16 + fr;
@@ -302,6 +361,31 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_ige
         const int b = m / HoWo, r = m - b * HoWo;
         const long opix = (long)b * a.out_bs + a.out_ro + r;
         float v[16];
+        if constexpr (SPLIT) {
+            scale_bias_act16(acc[0][mi], acc[1][mi], acc[2][mi], acc[3][mi], bv, sc, a.act != 0, v);
+            if (!a.out_f32) {
+                f16* dst = reinterpret_cast<f16*>(a.out) + opix * a.out_ct + a.out_coff + cbase;
+                const f16* rp = a.res ? reinterpret_cast<const f16*>(a.res) + (long)m * a.res_ct + a.res_coff + cbase : nullptr;
+                if (cbase + 16 <= a.Cout) {
+                    if (rp) {
+                        const f16x8 r0v = *reinterpret_cast<const f16x8*>(rp), r1v = *reinterpret_cast<const f16x8*>(rp + 8);
+                        const f16x8 q0v = *reinterpret_cast<const f16x8*>(rp + a.res_lo), q1v = *reinterpret_cast<const f16x8*>(rp + a.res_lo + 8);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { v[j] += (float)r0v[j] + (float)q0v[j]; v[8 + j] += (float)r1v[j] + (float)q1v[j]; }
+                    }
+                    store_split16(dst, a.out_lo, v);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        if (cbase + j >= a.Cout) continue;
+                        float x = v[j];
+                        if (rp) x += (float)rp[j] + (float)rp[a.res_lo + j];
+                        store_split1(dst + j, a.out_lo, x);
+                    }
+                }
+                continue;
+            }
+        } else {
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
@@ -310,6 +394,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_ige
                 if (a.act) x = (sizeof(T) == 2) ? silu_fast(x) : silu_exact(x);
                 v[ni * 4 + j] = x;
             }
+        }
         const bool full = (cbase + 16 <= a.Cout) && !a.out_f32;
         if (full) {
             T* dst = reinterpret_cast<T*>(a.out) + opix * a.out_ct + a.out_coff + cbase;
@@ -1236,8 +1321,10 @@ static hipError_t launch_halo2(const ConvArgs& a, hipStream_t s) {
 // per wave and stage, 32 MFMAs per wave between barriers.
 // DUAL = true: maps at most 16 pixels wide (the stride-32 level of a 512-px tile): the 32 patch columns are the 16 columns of
 // TWO consecutive images, each with its own left/right halo column (patch rows of 36 instead of 34 pixels).
-template <bool TAIL, int WN, bool DUAL = false, int TPS = 2>
+template <bool TAIL, int WN, bool DUAL = false, int TPS = 2, bool SPLIT = false>
 __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
+    // SPLIT (fp16x3 context): three passes over the input channels -- halo slabs of [x_hi | x_lo | x_hi] against the weight
+    // slabs [w_hi | w_hi | w_lo] of the packed copy, i.e. the same stage loop over 3x the slab pairs; scaled / split epilogue
     // TPS = taps per stage (between two barriers): 2, or 3 (WN = 2 only: six stages of 96 MFMAs per slab pair, 152 KiB of LDS)
     static_assert(TPS == 2 || (TPS == 3 && WN == 2), "three taps per stage: 128-channel variant only");
     constexpr int NST = 18 / TPS;
@@ -1263,7 +1350,8 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
     const int ty = rest % tiles_y;
     const int b = rest / tiles_y;
     const int y0 = ty * TH, x0 = tx * TW, n0 = nt * BN;
-    const int pairs = a.Cin / 64;                           // pairs of 32-channel slabs
+    const int ppairs = a.Cin / 64;                          // pairs of 32-channel slabs in one pass over the input channels
+    const int pairs = SPLIT ? 3 * ppairs : ppairs;
     const bool stamps = CY_STAMPS_ENABLED && (a.dbg & 64) != 0;      // diagnostic builds: phase stamps of the workgroup
     const unsigned long long t_entry = stamps ? stamp_real() : 0;
 
@@ -1287,9 +1375,15 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
         woff = (unsigned)((n0 + row) * 64 + ((lane & 3) ^ (((row >> 2) & 1) << 1)) * 16);
     }
     auto dma_patch = [&](int buf, int slab) {               // slab: 32-channel slab index
+        unsigned so = (unsigned)slab * 64u;
+        if constexpr (SPLIT) {                               // virtual slab -> physical slab (+ the offset of the low halves in the middle pass)
+            int lo;
+            so = (unsigned)x3_chunk(slab, 2 * ppairs, lo) * 64u;
+            if (lo) so += (unsigned)a.in0_lo * 2u;
+        }
 #pragma unroll
         for (int j = 0; j < PROUNDS; ++j)                    // uniform part in soffset: not range-checked, so the OOB sentinel of
-            dma_piece(rs0, (lds_ptr_t*)(Pbuf + buf * P_BYTES + (j * NW + wave) * 1024), poff[j], slab * 64);   // a lane survives it
+            dma_piece(rs0, (lds_ptr_t*)(Pbuf + buf * P_BYTES + (j * NW + wave) * 1024), poff[j], so);   // a lane survives it
     };
     auto dma_stage = [&](int ring, int slab0, int u0) {     // taps u0 .. u0+TPS-1 of the pair starting at slab slab0 (u in 0..17)
         if constexpr (WN == 2) {
@@ -1468,6 +1562,72 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
 
     const unsigned long long t_epi = stamps ? stamp_real() : 0, c_epi = stamps ? stamp_now() : 0;
     const int cbase = n0 + wn * 64 + fq * 16;
+    if constexpr (SPLIT) {
+        // fp16x3 epilogue: acc * oscale + bias, SiLU, residual = its high + low halves (requested two pixel fragments at a
+        // time: the accumulators leave no room for more), result stored as high / low halves
+        float bv[16], sc[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(bias_lds + wn * 64 + fq * 16 + j * 4);
+            bv[j * 4] = t[0]; bv[j * 4 + 1] = t[1]; bv[j * 4 + 2] = t[2]; bv[j * 4 + 3] = t[3];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sc[j] = a.oscale[cbase + j];
+        const bool vec = cbase + 16 <= a.Cout;
+        const bool res_vec = a.res != nullptr && vec;
+        const auto rsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.res ? a.res : a.out), 0,
+                                                           a.res ? (unsigned)((long)a.B * H * W * a.res_ct * 2) : 0u, 0x00020000);
+#pragma unroll
+        for (int g4 = 0; g4 < MIW; g4 += 2) {
+            f16x8 rv[2][4];
+            if (res_vec) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int mi = g4 + m;
+                    const int y = y0 + wm * RPW + (mi >> 1), x = DUAL ? fr : x0 + (mi & 1) * 16 + fr;
+                    const int bb = DUAL ? 2 * b + (mi & 1) : b;
+                    const bool ok = y < H && x < W && bb < a.B;
+                    const unsigned ro = ok ? (unsigned)((((bb * H + y) * W + x) * a.res_ct + a.res_coff + cbase) * 2) : CY_OOB;
+                    rv[m][0] = __builtin_bit_cast(f16x8, load_b128(rsr, ro, 0));
+                    rv[m][1] = __builtin_bit_cast(f16x8, load_b128(rsr, ro, 16));
+                    rv[m][2] = __builtin_bit_cast(f16x8, load_b128(rsr, ro, a.res_lo * 2));
+                    rv[m][3] = __builtin_bit_cast(f16x8, load_b128(rsr, ro, a.res_lo * 2 + 16));
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int mi = g4 + m;
+                const int y = y0 + wm * RPW + (mi >> 1), x = DUAL ? fr : x0 + (mi & 1) * 16 + fr;
+                const int bb = DUAL ? 2 * b + (mi & 1) : b;
+                if (y >= H || x >= W || bb >= a.B) continue;
+                const long pix = ((long)bb * H + y) * W + x;
+                float v[16];
+                scale_bias_act16(acc[0][mi], acc[1][mi], acc[2][mi], acc[3][mi], bv, sc, a.act != 0, v);
+                f16* dst = reinterpret_cast<f16*>(a.out) + pix * a.out_ct + a.out_coff + cbase;
+                if (vec) {
+                    if (res_vec) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            v[j] += (float)rv[m][0][j] + (float)rv[m][2][j];
+                            v[8 + j] += (float)rv[m][1][j] + (float)rv[m][3][j];
+                        }
+                    }
+                    store_split16(dst, a.out_lo, v);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        if (cbase + j >= a.Cout) continue;
+                        float t = v[j];
+                        if (a.res) {
+                            const f16* rp = reinterpret_cast<const f16*>(a.res) + pix * a.res_ct + a.res_coff + cbase + j;
+                            t += (float)rp[0] + (float)rp[a.res_lo];
+                        }
+                        store_split1(dst + j, a.out_lo, t);
+                    }
+                }
+            }
+        }
+    } else {
     // Residual (bottleneck shortcut): all of this wave's 2*MIW vectors are requested up front (the fragment registers are
     // free now), so the epilogue pays ONE memory round trip instead of one per pixel fragment (1 workgroup per CU: nothing
     // else hides it).  Out-of-range pixels read the zero of the buffer range check.
@@ -1521,6 +1681,7 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
             }
         }
     }
+    }
     // diagnostic builds: one record per workgroup (wave 0, plain stores; units of 10 ns): [0] entry -> loop (address setup, prologue
     // round trip), [1] stage loop, [2] epilogue issue, [3] the stage loop again in s_memtime ticks (clock = [3] / [1]).  (Summing with atomics from 16k waves stretched the
     // kernel 4x and the epilogue figures with it.)
@@ -1535,21 +1696,21 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
     }
 }
 
-template <int WN, bool DUAL = false, int TPS = 2>
+template <int WN, bool DUAL = false, int TPS = 2, bool SPLIT = false>
 static hipError_t launch_wide(const ConvArgs& a, hipStream_t s) {
     constexpr int PR = 18 * (DUAL ? 36 : 34), NPC = (PR + 15) / 16, PROUNDS = (NPC + 7) / 8, BN = 64 * WN;
     const size_t lds = 2 * PROUNDS * 8 * 1024 + 3 * TPS * BN * 64 + 1024;       // halo x2, weight ring, bias
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wide_kernel<false, WN, DUAL, TPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wide_kernel<true, WN, DUAL, TPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wide_kernel<false, WN, DUAL, TPS, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wide_kernel<true, WN, DUAL, TPS, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const int bx = DUAL ? (a.B + 1) / 2 : a.B * ((a.Wi + 31) / 32);
     const int blocks = bx * ((a.Hi + 15) / 16) * ((pad64(a.Cout) + BN - 1) / BN);
     static const int tail = getenv("CY_WIDE_TAIL") ? atoi(getenv("CY_WIDE_TAIL")) : 1;
-    if (tail) hipLaunchKernelGGL((conv3x3_wide_kernel<true, WN, DUAL, TPS>), dim3(blocks), dim3(512), lds, s, a);
-    else hipLaunchKernelGGL((conv3x3_wide_kernel<false, WN, DUAL, TPS>), dim3(blocks), dim3(512), lds, s, a);
+    if (tail) hipLaunchKernelGGL((conv3x3_wide_kernel<true, WN, DUAL, TPS, SPLIT>), dim3(blocks), dim3(512), lds, s, a);
+    else hipLaunchKernelGGL((conv3x3_wide_kernel<false, WN, DUAL, TPS, SPLIT>), dim3(blocks), dim3(512), lds, s, a);
     return hipGetLastError();
 }
 
@@ -1562,8 +1723,10 @@ static hipError_t launch_wide(const ConvArgs& a, hipStream_t s) {
 // chunks ahead, counted vmcnt).  A wave owns MI*16 pixels x all BN = 64*NB channels of the workgroup's tile:
 //   per 64-channel K chunk and wave: NB DMA pieces + 2*MI register loads for 8*NB*MI MFMAs (NB=4, MI=2: 8 for 64).
 // Also handles the two-segment input (nearest-x2 upsample + concat) of layers 12 and 15: per-lane addresses anyway.
-template <int NB, int MI, int RING, bool K3>
+template <int NB, int MI, int RING, bool K3, bool SPLIT = false>
 __global__ __launch_bounds__(512, (NB * MI <= 4 && RING == 2) ? 2 : 1) void conv1x1_direct_kernel(const ConvArgs a) {
+    // SPLIT (fp16x3 context): three passes over the K chunks -- pixels [x_hi | x_lo | x_hi] (the low halves a.in*_lo halves behind
+    // the high ones) against the packed weight chunks [w_hi | w_hi | w_lo]; scaled / split epilogue
     constexpr int NW = 8, BN = 64 * NB, BM = NW * MI * 16, W_BYTES = BN * 128, DIST = RING - 1;
     constexpr int WPW = BN / 8 / NW, APW = 2 * MI, PER = WPW + APW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1584,7 +1747,8 @@ __global__ __launch_bounds__(512, (NB * MI <= 4 && RING == 2) ? 2 : 1) void conv
     // whose tap falls outside the image get the OOB sentinel in voffset (the only part that is range-checked) -> zeros.
     // K3 = false is the plain 1x1 kernel: none of the tap arithmetic is compiled in.
     constexpr int taps = K3 ? 9 : 1, pad = K3 ? 1 : 0, kk3 = K3 ? 3 : 1;
-    const int chunks = (a.Cin / 64) * taps, c0chunks = a.c1 ? a.c0 / 64 : chunks;
+    const int pchunks = (a.Cin / 64) * taps, c0chunks = a.c1 ? a.c0 / 64 : pchunks;     // chunks of one pass; of its first segment
+    const int chunks = SPLIT ? 3 * pchunks : pchunks;
     const unsigned bias_bytes = K3 ? (unsigned)((a.Wi + 1) * a.in0_ct) * 2u : 0u;
 
     // (num_records widened by the bias so that the check passes whether or not the hardware adds soffset before it)
@@ -1624,29 +1788,32 @@ __global__ __launch_bounds__(512, (NB * MI <= 4 && RING == 2) ? 2 : 1) void conv
     }
     u32x4 xa[RING][MI][2];
     int ltap = 0, lslab = 0;                                // cursor of load_a (called for c = 0, 1, 2, ... in order)
-    auto load_a = [&](int slot, int c) {                    // the uniform part of the address rides in soffset (not range-checked)
+    auto load_a = [&](int slot, int cv) {                   // the uniform part of the address rides in soffset (not range-checked)
+        int lo = 0;
+        const int c = SPLIT ? x3_chunk(cv, pchunks, lo) : cv;           // physical chunk (the weights are packed per virtual chunk)
+        const unsigned lo0 = SPLIT && lo ? (unsigned)a.in0_lo * 2u : 0u, lo1 = SPLIT && lo ? (unsigned)a.in1_lo * 2u : 0u;
         if (c >= c0chunks) {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk)
-                    xa[slot][mi][kk] = load_b128(rs1, v1[mi], ((c - c0chunks) * 64 + kk * 32) * 2);
+                    xa[slot][mi][kk] = load_b128(rs1, v1[mi], ((c - c0chunks) * 64 + kk * 32) * 2 + lo1);
         } else if constexpr (!K3) {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk)
-                    xa[slot][mi][kk] = load_b128(rs0, v0[mi], (c * 64 + kk * 32) * 2);
+                    xa[slot][mi][kk] = load_b128(rs0, v0[mi], (c * 64 + kk * 32) * 2 + lo0);
         } else {
             const int kh = ltap / 3, kw = ltap - kh * 3;
-            const unsigned so = bias_bytes + (unsigned)((((kh - 1) * a.Wi + (kw - 1)) * a.in0_ct + lslab * 64) * 2);
+            const unsigned so = bias_bytes + (unsigned)((((kh - 1) * a.Wi + (kw - 1)) * a.in0_ct + lslab * 64) * 2) + lo0;
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
                 const unsigned vo = ((vmask[mi] >> ltap) & 1u) ? v0[mi] : CY_OOB;
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) xa[slot][mi][kk] = load_b128(rs0, vo, so + kk * 64);
             }
-            if (++ltap == 9) { ltap = 0; ++lslab; }
+            if (++ltap == 9) { ltap = 0; ++lslab; if (SPLIT && lslab * 9 == pchunks) lslab = 0; }
         }
     };
     auto dma_w = [&](int slot, int c) {
@@ -1735,6 +1902,11 @@ __global__ __launch_bounds__(512, (NB * MI <= 4 && RING == 2) ? 2 : 1) void conv
             const f32x4 t = *reinterpret_cast<const f32x4*>(bias_lds + g * 64 + fq * 16 + j * 4);
             bv[j * 4] = t[0]; bv[j * 4 + 1] = t[1]; bv[j * 4 + 2] = t[2]; bv[j * 4 + 3] = t[3];
         }
+        float sc[SPLIT ? 16 : 1];
+        if constexpr (SPLIT) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) sc[j] = a.oscale[cbase + j];
+        }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int m = m0 + (wave * MI + mi) * 16 + fr;
@@ -1742,6 +1914,29 @@ __global__ __launch_bounds__(512, (NB * MI <= 4 && RING == 2) ? 2 : 1) void conv
             const int b = m / HoWo, r = m - b * HoWo;
             const long opix = (long)b * a.out_bs + a.out_ro + r;
             float v[16];
+            if constexpr (SPLIT) {
+                scale_bias_act16(acc[g * 4][mi], acc[g * 4 + 1][mi], acc[g * 4 + 2][mi], acc[g * 4 + 3][mi], bv, sc, a.act != 0, v);
+                f16* dst = reinterpret_cast<f16*>(a.out) + opix * a.out_ct + a.out_coff + cbase;
+                const f16* rp = a.res ? reinterpret_cast<const f16*>(a.res) + (long)m * a.res_ct + a.res_coff + cbase : nullptr;
+                if (cbase + 16 <= a.Cout) {
+                    if (rp) {
+                        const f16x8 r0v = *reinterpret_cast<const f16x8*>(rp), r1v = *reinterpret_cast<const f16x8*>(rp + 8);
+                        const f16x8 q0v = *reinterpret_cast<const f16x8*>(rp + a.res_lo), q1v = *reinterpret_cast<const f16x8*>(rp + a.res_lo + 8);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { v[j] += (float)r0v[j] + (float)q0v[j]; v[8 + j] += (float)r1v[j] + (float)q1v[j]; }
+                    }
+                    store_split16(dst, a.out_lo, v);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        if (cbase + j >= a.Cout) continue;
+                        float t = v[j];
+                        if (rp) t += (float)rp[j] + (float)rp[a.res_lo + j];
+                        store_split1(dst + j, a.out_lo, t);
+                    }
+                }
+                continue;
+            }
             bias_act16(acc[g * 4][mi], acc[g * 4 + 1][mi], acc[g * 4 + 2][mi], acc[g * 4 + 3][mi], bv, a.act != 0, v);
             if (cbase + 16 <= a.Cout) {
                 f16* dst = reinterpret_cast<f16*>(a.out) + opix * a.out_ct + a.out_coff + cbase;
@@ -1774,18 +1969,18 @@ __global__ __launch_bounds__(512, (NB * MI <= 4 && RING == 2) ? 2 : 1) void conv
     }
 }
 
-template <int NB, int MI, int RING, bool K3>
+template <int NB, int MI, int RING, bool K3, bool SPLIT = false>
 static hipError_t launch_direct(const ConvArgs& a, hipStream_t s) {
     constexpr int BN = 64 * NB, BM = 8 * MI * 16;
     const size_t lds = RING * BN * 128 + 1024;             // weight ring, bias
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_direct_kernel<NB, MI, RING, K3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_direct_kernel<NB, MI, RING, K3, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const int M = a.B * a.Ho * a.Wo;
     const int blocks = ((M + BM - 1) / BM) * ((pad64(a.Cout) + BN - 1) / BN);
-    hipLaunchKernelGGL((conv1x1_direct_kernel<NB, MI, RING, K3>), dim3(blocks), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((conv1x1_direct_kernel<NB, MI, RING, K3, SPLIT>), dim3(blocks), dim3(512), lds, s, a);
     return hipGetLastError();
 }
 
@@ -1804,7 +1999,7 @@ static hipError_t launch_halo(const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <typename T, int WM, int WN, int MI, int NSTAGE = 2>
+template <typename T, int WM, int WN, int MI, int NSTAGE = 2, bool SPLIT = false>
 static hipError_t launch_t(const ConvArgs& a, hipStream_t s) {
     constexpr int BM = WM * MI * 16, BN = WN * 64;
     const int M = a.B * a.Ho * a.Wo;
@@ -1812,11 +2007,11 @@ static hipError_t launch_t(const ConvArgs& a, hipStream_t s) {
     const size_t lds = NSTAGE * (BM + BN) * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, WM, WN, MI, NSTAGE>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, WM, WN, MI, NSTAGE, SPLIT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, MI, NSTAGE>), dim3(ntm * ntn), dim3(WM * WN * 64), lds, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, MI, NSTAGE, SPLIT>), dim3(ntm * ntn), dim3(WM * WN * 64), lds, s, a);
     return hipGetLastError();
 }
 
@@ -1841,7 +2036,26 @@ static bool s2_direct() { static const int v = getenv("CY_S2_DIRECT") ? atoi(get
 // between batch sizes.
 bool batch_invariant() { const char* e = getenv("CY_BATCH_INVARIANT"); return !e || atoi(e) != 0; }
 
+// fp16x3 context: the kernels that carry the three-pass K walk -- the 512-px wide 3x3 kernel (128- / 64-channel / dual-image forms),
+// the pixels-direct 1x1 / strided-3x3 kernel and the generic implicit GEMM for everything else.  The choice depends on the layer's
+// geometry only (never on the batch), so a tile's result does not depend on the batch it travels in.
+static int conv_variant_x3(const ConvArgs& a) {
+    const bool narrow = pad64(a.Cout) <= 64;
+    if (a.k == 3 && a.s == 1 && a.c1 == 0 && !a.up0 && !a.out_f32 && a.Cin % 64 == 0 && a.wgt32 && a.out_bs == a.Ho * a.Wo && a.out_ro == 0) {
+        const int wpad = (a.Wi + 31) / 32 * 32;
+        const bool fits = (wpad - a.Wi) * 8 <= a.Wi;
+        if (narrow && a.Wi % 32 == 0) return CONV_WIDE_64;
+        if (!narrow && fits) return CONV_WIDE_128;
+        if (!narrow && a.Wi <= 16 && a.Wi >= 14) return CONV_WIDE_DUAL;
+    }
+    if (!a.out_f32 && a.Cin % 64 == 0 && !narrow &&
+        ((a.k == 1 && a.s == 1 && (a.c1 == 0 || a.c0 % 64 == 0)) || (a.k == 3 && a.s == 2 && a.c1 == 0 && !a.up0)))
+        return pad64(a.Cout) >= 256 ? CONV_DIRECT_256 : CONV_DIRECT_128;
+    return narrow ? CONV_GENERIC_64 : CONV_GENERIC_128;
+}
+
 int conv_variant(Precision p, const ConvArgs& a) {
+    if (p == PREC_F16X3) return conv_variant_x3(a);
     const bool narrow = pad64(a.Cout) <= 64;
     const long Bv = batch_invariant() && a.B < 256 ? 256 : a.B;     // the batch size the thresholds see
     // 3x3 stride-1 layers (fp16 context; the fp32 parity context keeps the generic kernel): halo-reuse kernels.
@@ -1893,6 +2107,18 @@ int conv_variant(Precision p, const ConvArgs& a) {
 }
 
 hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s) {
+    if (p == PREC_F16X3) {
+        if (!a.split || !a.oscale) return hipErrorInvalidValue;
+        switch (conv_variant_x3(a)) {
+            case CONV_WIDE_128: return launch_wide<2, false, 2, true>(a, s);
+            case CONV_WIDE_64: return launch_wide<1, false, 2, true>(a, s);
+            case CONV_WIDE_DUAL: return launch_wide<2, true, 2, true>(a, s);
+            case CONV_DIRECT_256: return a.k == 3 ? launch_direct<4, 2, 3, true, true>(a, s) : launch_direct<4, 2, 3, false, true>(a, s);
+            case CONV_DIRECT_128: return a.k == 3 ? launch_direct<2, 4, 2, true, true>(a, s) : launch_direct<2, 2, 2, false, true>(a, s);
+            case CONV_GENERIC_64: return launch_t<f16, 4, 1, 2, 2, true>(a, s);
+            default: return launch_t<f16, 2, 2, 4, 2, true>(a, s);
+        }
+    }
     switch (conv_variant(p, a)) {
         case CONV_C64_PERSIST: return a.Cin == 32 ? launch_c64<32>(a, s) : launch_c64<64>(a, s);
         case CONV_PP_64: return launch_pp<2>(a, s);
@@ -1974,10 +2200,72 @@ void pack_weights(Precision p, const float* W, int cout, int cin, int k, void* d
     (void)chunks;
 }
 
+// fp16x3 context.  Per output channel n the filter is scaled by 2^e(n) so that its largest weight lies in [2^13, 2^14): the low
+// halves w_lo = fp16(w' - fp16(w')) of all but vanishing weights are then normal fp16 numbers (unscaled they would sit in the
+// subnormal range and carry ~3e-6 relative error); oscale[n] = 2^-e(n) multiplies the accumulator in the epilogue (exact).
+// K holds three passes over the (chunk-padded) input channels: w_hi, w_hi, w_lo -- against x_hi, x_lo, x_hi.
+size_t packed_weight_bytes_x3(int cout, int cin, int k, int chunk_bytes) {
+    const int epb = chunk_bytes / 2;
+    return packed_weight_bytes(PREC_F16, cout, 3 * ((cin + epb - 1) / epb * epb), k, chunk_bytes);
+}
+
+void pack_weights_x3(const float* W, int cout, int cin, int k, void* dst, float* oscale, int chunk_bytes) {
+    const int taps = k * k, epb = chunk_bytes / 2, cinp = (cin + epb - 1) / epb * epb, cp = pad128(cout);
+    memset(dst, 0, packed_weight_bytes_x3(cout, cin, k, chunk_bytes));
+    for (int i = 0; i < cp; ++i) oscale[i] = 1.0f;
+    f16* o = reinterpret_cast<f16*>(dst);
+    for (int row = 0; row < cp; ++row) {
+        const int blk = row >> 6, ni = (row >> 4) & 3, rr = row & 15;
+        const int n = blk * 64 + (rr >> 2) * 16 + ni * 4 + (rr & 3);      // channel held by packed row `row`
+        if (n >= cout) continue;
+        float m = 0.0f;
+        for (size_t i = 0; i < (size_t)cin * taps; ++i) m = fmaxf(m, fabsf(W[(size_t)n * cin * taps + i]));
+        int e = 0;
+        if (m > 0.0f && std::isfinite(m)) { int ex; frexpf(m, &ex); e = 14 - ex; }       // m = f * 2^ex, f in [0.5, 1): m * 2^e in [2^13, 2^14)
+        if (e > 60) e = 60;
+        if (e < -60) e = -60;
+        const float up = ldexpf(1.0f, e);
+        oscale[n] = ldexpf(1.0f, -e);
+        for (int t = 0; t < taps; ++t)
+            for (int c = 0; c < cin; ++c) {
+                const float v = W[((size_t)n * cin + c) * taps + t] * up;
+                const f16 hi = (f16)v, lo = (f16)(v - (float)hi);
+                for (int pass = 0; pass < 3; ++pass) {
+                    const int cv = pass * cinp + c;
+                    o[(((size_t)(cv / epb) * taps + t) * cp + row) * epb + (cv % epb)] = pass == 2 ? lo : hi;
+                }
+            }
+    }
+}
+
+// fp32 NHWC <-> high / low halves (kernel-level test entry and debug reads of the fp16x3 context)
+__global__ __launch_bounds__(256) void x3_split_kernel(const float* __restrict__ in, f16* __restrict__ out, long n, int C) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long pix = i / C; const int c = (int)(i - pix * C);
+        store_split1(out + pix * 2 * C + c, C, in[i]);
+    }
+}
+__global__ __launch_bounds__(256) void x3_merge_kernel(const f16* __restrict__ in, float* __restrict__ out, long n, int C) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long pix = i / C; const int c = (int)(i - pix * C);
+        out[i] = (float)in[pix * 2 * C + c] + (float)in[pix * 2 * C + C + c];
+    }
+}
+hipError_t launch_x3_split(const float* in, void* out, long npix, int C, hipStream_t s) {
+    const long n = npix * C;
+    hipLaunchKernelGGL(x3_split_kernel, dim3((unsigned)((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535)), dim3(256), 0, s, in, reinterpret_cast<f16*>(out), n, C);
+    return hipGetLastError();
+}
+hipError_t launch_x3_merge(const void* in, float* out, long npix, int C, hipStream_t s) {
+    const long n = npix * C;
+    hipLaunchKernelGGL(x3_merge_kernel, dim3((unsigned)((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535)), dim3(256), 0, s, reinterpret_cast<const f16*>(in), out, n, C);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ stem
 // Layer 0: Conv(3, C, 3, 2) on the NHWC4 network input.  K = 27 is too small for the matrix cores to matter; the
 // layer is bound by its 64-channel output write.  One thread = one output pixel x 16 output channels.
-template <typename T>
+template <typename T, bool SPLIT = false>      // SPLIT (fp16x3 context): T = float input, output as fp16 high / low halves
 __global__ __launch_bounds__(256) void stem_kernel(const StemArgs a) {
     __shared__ float w[27 * 64];
     __shared__ float bs[64];
@@ -2013,6 +2301,13 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemArgs a) {
         for (int t = 0; t < 27; ++t)
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[j] = fmaf(x[t], w[t * a.Cout + cb * 16 + j], acc[j]);
+        if constexpr (SPLIT) {
+            float v16[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v16[j] = silu_fast(acc[j] + bs[cb * 16 + j]);
+            store_split16(reinterpret_cast<f16*>(a.out) + pix * a.out_ct + a.out_coff + cb * 16, a.out_lo, v16);
+            continue;
+        }
         T* dst = reinterpret_cast<T*>(a.out) + pix * a.out_ct + a.out_coff + cb * 16;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -2096,6 +2391,7 @@ hipError_t launch_stem(Precision p, const StemArgs& a, hipStream_t s) {
     const long total = (long)a.B * a.Ho * a.Wo * (a.Cout / 16);
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     if (p == PREC_F16) hipLaunchKernelGGL(stem_kernel<f16>, dim3(grid), dim3(256), 0, s, a);
+    else if (p == PREC_F16X3) hipLaunchKernelGGL((stem_kernel<float, true>), dim3(grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(stem_kernel<float>, dim3(grid), dim3(256), 0, s, a);
     return hipGetLastError();
 }
@@ -2522,7 +2818,42 @@ __global__ __launch_bounds__(256) void pool5_kernel(const PoolArgs a) {
     }
 }
 
+// fp16x3 context: the maximum of hi + lo, stored as the halves of the winning pixel (a max picks one of its inputs, so no rounding)
+__global__ __launch_bounds__(256) void pool5_x3_kernel(const PoolArgs a) {
+    const int cv = a.C / 8;
+    const long total = (long)a.B * a.H * a.W * cv;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % cv) * 8;
+        const long pix = idx / cv;
+        const int w = (int)(pix % a.W), h = (int)((pix / a.W) % a.H), b = (int)(pix / ((long)a.W * a.H));
+        float m[8]; f16x8 mh, ml;
+        bool first = true;
+        for (int dh = -2; dh <= 2; ++dh)
+            for (int dw = -2; dw <= 2; ++dw) {
+                const int hh = h + dh, ww = w + dw;
+                if ((unsigned)hh >= (unsigned)a.H || (unsigned)ww >= (unsigned)a.W) continue;
+                const f16* sp = reinterpret_cast<const f16*>(a.src) + (((long)b * a.H + hh) * a.W + ww) * a.ct + a.src_coff + c;
+                const f16x8 vh = *reinterpret_cast<const f16x8*>(sp), vl = *reinterpret_cast<const f16x8*>(sp + a.lo);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float v = (float)vh[j] + (float)vl[j];
+                    if (first || v > m[j]) { m[j] = v; mh[j] = vh[j]; ml[j] = vl[j]; }
+                }
+                first = false;
+            }
+        f16* dp = reinterpret_cast<f16*>(a.dst) + pix * a.ct + a.dst_coff + c;
+        *reinterpret_cast<f16x8*>(dp) = mh;
+        *reinterpret_cast<f16x8*>(dp + a.lo) = ml;
+    }
+}
+
 hipError_t launch_pool5(Precision p, const PoolArgs& a, hipStream_t s) {
+    if (p == PREC_F16X3) {
+        if (a.C % 8 || a.lo <= 0) return hipErrorInvalidValue;
+        const long total = (long)a.B * a.H * a.W * (a.C / 8);
+        hipLaunchKernelGGL(pool5_x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
     const int V = p == PREC_F16 ? 8 : 4;
     if (a.C % V) return hipErrorInvalidValue;
     const long total = (long)a.B * a.H * a.W * (a.C / V);

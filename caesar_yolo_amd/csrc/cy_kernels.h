@@ -18,7 +18,12 @@ namespace cy {
 inline int env_knob(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 inline int dev_knob(const char* name, int dflt) { return CY_DEV_KNOBS ? env_knob(name, dflt) : dflt; }
 
-enum Precision { PREC_F16 = 0, PREC_F32 = 1 };
+// PREC_F16X3 ("fp16x3", the fast parity context): every activation is stored as TWO fp16 values hi = fp16(x), lo = fp16(x - hi)
+// (22 significand bits), weights likewise after a per-output-channel power-of-two scale that keeps their low halves out of the
+// fp16 subnormal range; a product x*w is evaluated as hi*hi + lo*hi + hi*lo on the fp16 matrix cores with fp32 accumulation
+// (the dropped lo*lo term is 2^-22 relative), i.e. a layer is the tuned fp16 kernel over 3x the K.  Activation buffers keep the
+// NHWC channel-slice scheme with 2*C halves per pixel: [C high halves | C low halves].
+enum Precision { PREC_F16 = 0, PREC_F32 = 1, PREC_F16X3 = 2 };
 
 // One fused Conv2d(+folded BN bias)(+SiLU)(+residual) over NHWC activations, as an implicit GEMM:
 //   out[pix, n] = act( sum_{tap,c} in[pix(tap), c] * w[n, tap, c] + bias[n] ) (+ res[pix, n])
@@ -37,6 +42,11 @@ struct ConvArgs {
     int B, Hi, Wi, Ho, Wo, Cin, Cout, k, s, act;
     uint32_t in0_bytes, in1_bytes, wgt_bytes;          // buffer extents for the hardware range check
     int dbg;                                           // developer ablation bits (0 in production)
+    // fp16x3 context (split != 0): *_ct are in halves (2 * channels of the tensor); the low halves of a slice sit *_lo halves behind
+    // its high halves.  wgt / wgt32 then hold 3 passes over K: [w_hi | w_hi | w_lo] against inputs [x_hi | x_lo | x_hi]; oscale[n] is
+    // the power of two that undoes the weight scale of output channel n (applied to the accumulator before the bias).
+    int split, in0_lo, in1_lo, out_lo, res_lo;
+    const float* oscale;                               // [Cout_pad128] or null
 };
 
 // First layer (Cin = 3 stored as 4, k=3, s=2): direct convolution.
@@ -44,6 +54,7 @@ struct StemArgs {
     const void* in; void* out; const float* w; const float* bias;   // w: [27][Cout] fp32 (tap-major, then c)
     const void* wpk;                                                // fp16 context: [64][32] packed panel (pack_stem_weights)
     int B, Hi, Wi, Ho, Wo, Cout, out_ct, out_coff;
+    int out_lo;                                                     // fp16x3 context: fp32 input, output as high / low halves (see ConvArgs)
 };
 
 // model.0 + model.1 of the YOLOv8/YOLO11 graphs in one kernel (fp16 context): the 64-channel half-resolution map (8 MB
@@ -72,6 +83,7 @@ void pack_bneck_weights(const float* W1, const float* W2, void* dst);      // W:
 
 struct PoolArgs {   // MaxPool2d(5,1,2) on a channel slice of an NHWC buffer, -inf padding
     const void* src; void* dst; int ct, src_coff, dst_coff, C, B, H, W;
+    int lo;                                            // fp16x3 context: offset of the low halves (0: plain)
 };
 
 // YOLO11 operators (cy_extra.hip)
@@ -104,6 +116,12 @@ hipError_t launch_pool5(Precision p, const PoolArgs& a, hipStream_t s);
 //   so that MFMA row (ni, rr) holds channel 64*blk + 16*(rr>>2) + 4*ni + (rr&3).
 size_t packed_weight_bytes(Precision p, int cout, int cin, int k, int chunk_bytes = 128);
 void pack_weights(Precision p, const float* W, int cout, int cin, int k, void* dst, int chunk_bytes = 128);
+// fp16x3 context: scaled [hi | hi | lo] passes (each pass padded to whole K chunks); oscale: [pad128(cout)] floats, 2^-s per channel
+size_t packed_weight_bytes_x3(int cout, int cin, int k, int chunk_bytes = 128);
+void pack_weights_x3(const float* W, int cout, int cin, int k, void* dst, float* oscale, int chunk_bytes = 128);
+// fp32 NHWC [npix][C] <-> high/low halves [npix][2C] (test entry cy_conv_bn_silu, debug reads)
+hipError_t launch_x3_split(const float* in, void* out, long npix, int C, hipStream_t s);
+hipError_t launch_x3_merge(const void* in, float* out, long npix, int C, hipStream_t s);
 void pack_stem_weights(const float* W, int cout, void* dst);      // 64*32 fp16
 __host__ __device__ inline int pad64(int c) { return (c + 63) / 64 * 64; }
 __host__ __device__ inline int pad128(int c) { return (c + 127) / 128 * 128; }

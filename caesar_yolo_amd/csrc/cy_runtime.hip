@@ -13,6 +13,7 @@
 using namespace cy;
 
 struct DevConv { void* w = nullptr; float* bias = nullptr; size_t wbytes = 0; float* stem_w = nullptr; void* w32 = nullptr; size_t w32bytes = 0;
+                 float* oscale = nullptr;       // fp16x3 context: 2^-e per output channel (undoes the weight scale in the epilogue)
                  float* dw_w = nullptr;         // dw_w: depth-wise 3x3 weights [9][C] fp32 (YOLO11)
                  void* bneck = nullptr; };      // on a bottleneck's cv1: register-fragment weights of the fused cv1+cv2 kernel (bneck64.hip)
 
@@ -66,7 +67,8 @@ thread_local std::string g_err;
 int fail(cy_ctx* c, int code, const std::string& m) { if (c) c->err = m; g_err = m; return code; }
 #define HIPCHK(c, x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(c, CY_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-inline size_t esize(Precision p) { return p == PREC_F16 ? 2 : 4; }
+inline size_t esize(Precision p) { return p == PREC_F16 ? 2 : 4; }      // bytes per activation value (fp16x3: two fp16 halves)
+inline Precision io_prec(Precision p) { return p == PREC_F16X3 ? PREC_F32 : p; }   // type of the network input buffer
 
 int py_round_half_even(double x) {
     double f = std::floor(x), d = x - f;
@@ -84,7 +86,7 @@ size_t tensor_elems_per_tile(const Plan& p, int H, int W) {
 void free_all(cy_ctx* c) {
     for (auto e : c->ev_pool) hipEventDestroy(e);
     c->ev_pool.clear(); c->ev_used = 0; c->prof.clear();
-    for (auto& d : c->dconv) { if (d.w) hipFree(d.w); if (d.bias) hipFree(d.bias); if (d.stem_w) hipFree(d.stem_w); if (d.w32) hipFree(d.w32); if (d.dw_w) hipFree(d.dw_w); if (d.bneck) hipFree(d.bneck); }
+    for (auto& d : c->dconv) { if (d.w) hipFree(d.w); if (d.bias) hipFree(d.bias); if (d.stem_w) hipFree(d.stem_w); if (d.w32) hipFree(d.w32); if (d.dw_w) hipFree(d.dw_w); if (d.bneck) hipFree(d.bneck); if (d.oscale) hipFree(d.oscale); }
     c->dconv.clear();
     if (c->ws) hipFree(c->ws);
     c->ws = nullptr;
@@ -302,6 +304,24 @@ int upload_weights(cy_ctx* c, const void* buf, size_t nbytes) {
             continue;
         }
         if (ci % 8) return fail(c, CY_ERR_UNSUPPORTED, "conv input channels must be a multiple of 8: " + name);
+        if (c->prec == PREC_F16X3) {
+            std::vector<float> osc(cp);
+            dc.wbytes = packed_weight_bytes_x3(co, ci, k);
+            packed.resize(dc.wbytes);
+            pack_weights_x3(W, co, ci, k, packed.data(), osc.data());
+            HIPCHK(c, hipMalloc(&dc.w, dc.wbytes));
+            HIPCHK(c, hipMemcpy(dc.w, packed.data(), dc.wbytes, hipMemcpyHostToDevice));
+            HIPCHK(c, hipMalloc(&dc.oscale, 4 * cp));
+            HIPCHK(c, hipMemcpy(dc.oscale, osc.data(), 4 * cp, hipMemcpyHostToDevice));
+            if (k == 3 && s == 1 && ci % 64 == 0) {          // second copy with 64-byte K chunks (conv3x3_wide_kernel)
+                dc.w32bytes = packed_weight_bytes_x3(co, ci, k, 64);
+                packed.resize(dc.w32bytes);
+                pack_weights_x3(W, co, ci, k, packed.data(), osc.data(), 64);
+                HIPCHK(c, hipMalloc(&dc.w32, dc.w32bytes));
+                HIPCHK(c, hipMemcpy(dc.w32, packed.data(), dc.w32bytes, hipMemcpyHostToDevice));
+            }
+            continue;
+        }
         dc.wbytes = packed_weight_bytes(c->prec, co, ci, k);
         packed.resize(dc.wbytes);
         pack_weights(c->prec, W, co, ci, k, packed.data());
@@ -320,6 +340,9 @@ int upload_weights(cy_ctx* c, const void* buf, size_t nbytes) {
         const std::string bad = validate_plan(plan);
         if (!bad.empty()) { free_all(c); return fail(c, CY_ERR_IO, "malformed CYW2 plan: " + bad); }
     }
+    if (c->prec == PREC_F16X3)
+        for (const Op& o : plan.ops)
+            if (o.kind == OPK_DWCONV || o.kind == OPK_ATTN) { free_all(c); return fail(c, CY_ERR_UNSUPPORTED, "the fp16x3 context runs YOLOv8 plans only (no depth-wise / attention kernels yet): use fp32 or fp16"); }
     if (c->prec == PREC_F16) {
         std::vector<char> wf(BNECK_WFRAG_BYTES);
         for (size_t i = 0; i + 1 < plan.ops.size(); ++i) {
@@ -403,14 +426,14 @@ int cy_create(int device, const cy_config* cfg, cy_ctx** out) {
     if (!cfg || !out) return fail(nullptr, CY_ERR_ARG, "null argument");
     if (cfg->max_batch < 1 || cfg->max_h < 32 || cfg->max_w < 32 || cfg->max_h % 32 || cfg->max_w % 32)
         return fail(nullptr, CY_ERR_ARG, "max_batch >= 1 and max_h/max_w multiples of 32 required");
-    if (cfg->precision != CY_F16 && cfg->precision != CY_F32) return fail(nullptr, CY_ERR_ARG, "bad precision");
+    if (cfg->precision != CY_F16 && cfg->precision != CY_F32 && cfg->precision != CY_F16X3) return fail(nullptr, CY_ERR_ARG, "bad precision");
     int n = 0;
     const hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || device < 0 || device >= n)
         return fail(nullptr, CY_ERR_HIP, std::string("no such HIP device (this library has no CPU fallback): hipGetDeviceCount -> ") +
                                              hipGetErrorString(e) + ", " + std::to_string(n) + " device(s), requested " + std::to_string(device));
     cy_ctx* c = new cy_ctx();
-    c->device = device; c->cfg = *cfg; c->prec = cfg->precision == CY_F16 ? PREC_F16 : PREC_F32;
+    c->device = device; c->cfg = *cfg; c->prec = cfg->precision == CY_F16 ? PREC_F16 : (cfg->precision == CY_F16X3 ? PREC_F16X3 : PREC_F32);
     *out = c;
     return CY_OK;
 }
@@ -552,6 +575,8 @@ static int forward_on(cy_ctx* c, const void* d_netin, int B, int H, int W, float
     if (rc) return rc;
     const Plan& p = c->plan;
     const size_t es = esize(c->prec);
+    const bool x3 = c->prec == PREC_F16X3;
+    const int cm = x3 ? 2 : 1;                           // halves per activation value: pixel strides are cm * C, the low halves C behind
     const int A = cy_num_anchors(H, W);
     int a_off[3], acc = 0;
     for (int l = 0; l < 3; ++l) { a_off[l] = acc; acc += (H >> (3 + l)) * (W >> (3 + l)); }
@@ -654,13 +679,13 @@ static int forward_on(cy_ctx* c, const void* d_netin, int B, int H, int W, float
             StemArgs a{};
             a.in = tp(o.in0); a.out = tp(o.out); a.w = c->dconv[o.conv].stem_w; a.bias = c->dconv[o.conv].bias; a.wpk = c->dconv[o.conv].w;
             a.B = Bn; a.Hi = H >> ti.level; a.Wi = W >> ti.level; a.Ho = H >> to.level; a.Wo = W >> to.level;
-            a.Cout = p.convs[o.conv].cout; a.out_ct = to.C; a.out_coff = o.out_coff;
+            a.Cout = p.convs[o.conv].cout; a.out_ct = cm * to.C; a.out_coff = o.out_coff; a.out_lo = x3 ? to.C : 0;
             HIPCHK(c, launch_stem(c->prec, a, s));
             prof_done(CONV_NUM_VARIANTS, 2.0 * Bn * a.Ho * a.Wo * a.Cout * 27.0);
         } else if (o.kind == OPK_POOL) {
             const Tensor& t = p.tensors[o.in0];
             PoolArgs a{};
-            a.src = tp(o.in0); a.dst = tp(o.out); a.ct = t.C; a.src_coff = o.in0_coff; a.dst_coff = o.out_coff;
+            a.src = tp(o.in0); a.dst = tp(o.out); a.ct = cm * t.C; a.src_coff = o.in0_coff; a.dst_coff = o.out_coff; a.lo = x3 ? t.C : 0;
             a.C = o.c0; a.B = Bn; a.H = H >> t.level; a.W = W >> t.level;
             HIPCHK(c, launch_pool5(c->prec, a, s));
             prof_done(CONV_NUM_VARIANTS + 1, 0.0);
@@ -695,12 +720,13 @@ static int forward_on(cy_ctx* c, const void* d_netin, int B, int H, int W, float
                 const Tensor& tt = p.tensors[t];
                 return (uint32_t)((size_t)Bn * (H >> tt.level) * (W >> tt.level) * tt.C * es);
             };
-            a.in0 = tp(o.in0); a.in0_ct = t0.C; a.in0_coff = o.in0_coff; a.c0 = o.c0; a.up0 = o.up0;
+            a.in0 = tp(o.in0); a.in0_ct = cm * t0.C; a.in0_coff = o.in0_coff; a.c0 = o.c0; a.up0 = o.up0;
             a.in0_bytes = span(o.in0);
+            a.split = x3; a.in0_lo = t0.C; a.oscale = c->dconv[o.conv].oscale;
             int lev_in = o.up0 ? t0.level - 1 : t0.level;
             if (o.in1 >= 0) {
                 const Tensor& t1 = p.tensors[o.in1];
-                a.in1 = tp(o.in1); a.in1_ct = t1.C; a.in1_coff = o.in1_coff; a.c1 = o.c1; a.in1_bytes = span(o.in1);
+                a.in1 = tp(o.in1); a.in1_ct = cm * t1.C; a.in1_coff = o.in1_coff; a.c1 = o.c1; a.in1_bytes = span(o.in1); a.in1_lo = t1.C;
                 lev_in = t1.level;
             }
             a.wgt = c->dconv[o.conv].w; a.wgt_bytes = (uint32_t)c->dconv[o.conv].wbytes; a.bias = c->dconv[o.conv].bias;
@@ -710,11 +736,11 @@ static int forward_on(cy_ctx* c, const void* d_netin, int B, int H, int W, float
             a.Cin = d.cin; a.Cout = d.cout;
             if (o.out >= 0) {
                 const Tensor& to = p.tensors[o.out];
-                a.out = tp(o.out); a.out_ct = to.C; a.out_coff = o.out_coff; a.out_bs = a.Ho * a.Wo; a.out_ro = 0; a.out_f32 = 0;
+                a.out = tp(o.out); a.out_ct = cm * to.C; a.out_coff = o.out_coff; a.out_bs = a.Ho * a.Wo; a.out_ro = 0; a.out_f32 = 0; a.out_lo = to.C;
             } else {
                 a.out = d_pred; a.out_ct = 64 + p.nc; a.out_coff = o.pred_coff; a.out_bs = A; a.out_ro = a_off[o.pred_level]; a.out_f32 = 1;
             }
-            if (o.res >= 0) { a.res = tp(o.res); a.res_ct = p.tensors[o.res].C; a.res_coff = o.res_coff; }
+            if (o.res >= 0) { a.res = tp(o.res); a.res_ct = cm * p.tensors[o.res].C; a.res_coff = o.res_coff; a.res_lo = p.tensors[o.res].C; }
             HIPCHK(c, launch_conv(c->prec, a, s));
             prof_done(conv_variant(c->prec, a), 2.0 * Bn * a.Ho * a.Wo * (double)a.Cout * a.Cin * a.k * a.k);
         }
@@ -806,8 +832,12 @@ int cy_debug_read_conv(cy_ctx* c, const char* conv_name, float* h_out, size_t ca
         HIPCHK(c, hipMemcpy(host.data(), c->ws + c->toff[o.out], host.size(), hipMemcpyDeviceToHost));
         for (int b = 0; b < B; ++b) for (int h = 0; h < Ho; ++h) for (int w = 0; w < Wo; ++w) for (int ch = 0; ch < C; ++ch) {
             const size_t src = (((size_t)b * Ho + h) * Wo + w) * t.C + o.out_coff + ch;
-            const float v = c->prec == PREC_F16 ? (float)reinterpret_cast<_Float16*>(host.data())[src]
-                                                : reinterpret_cast<float*>(host.data())[src];
+            float v;
+            if (c->prec == PREC_F16X3) {
+                const _Float16* hp = reinterpret_cast<_Float16*>(host.data()) + (((size_t)b * Ho + h) * Wo + w) * 2 * t.C + o.out_coff + ch;
+                v = (float)hp[0] + (float)hp[t.C];
+            } else v = c->prec == PREC_F16 ? (float)reinterpret_cast<_Float16*>(host.data())[src]
+                                           : reinterpret_cast<float*>(host.data())[src];
             h_out[(((size_t)b * C + ch) * Ho + h) * Wo + w] = v;
         }
         if (dims4) { dims4[0] = B; dims4[1] = C; dims4[2] = Ho; dims4[3] = Wo; }
@@ -821,6 +851,49 @@ int cy_conv_bn_silu(cy_ctx* c, const void* d_in, int B, int Hi, int Wi, int Cin,
     if (!c || !d_in || !h_w || !h_b || !d_out) return fail(c, CY_ERR_ARG, "null argument");
     if ((k != 1 && k != 3) || (s != 1 && s != 2) || Cin % 8 || B < 1) return fail(c, CY_ERR_ARG, "unsupported conv geometry");
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->prec == PREC_F16X3) {
+        // fp16x3 context: caller tensors are fp32 NHWC; they are split into high / low halves here, the layer runs on the split
+        // kernels exactly as inside the forward pass, and the result is merged back to fp32
+        hipStream_t st = (hipStream_t)stream;
+        const int pad = k / 2, Ho = (Hi + 2 * pad - k) / s + 1, Wo = (Wi + 2 * pad - k) / s + 1, cp = (Cout + 127) / 128 * 128;
+        const size_t nin = (size_t)B * Hi * Wi, nout = (size_t)B * Ho * Wo;
+        const size_t wb = packed_weight_bytes_x3(Cout, Cin, k), wb32 = (k == 3 && s == 1 && Cin % 64 == 0) ? packed_weight_bytes_x3(Cout, Cin, k, 64) : 0;
+        std::vector<char> packed(wb), p32(wb32);
+        std::vector<float> osc(cp), bias(cp, 0.0f);
+        pack_weights_x3(h_w, Cout, Cin, k, packed.data(), osc.data());
+        if (wb32) pack_weights_x3(h_w, Cout, Cin, k, p32.data(), osc.data(), 64);
+        memcpy(bias.data(), h_b, 4 * Cout);
+        void *dw = nullptr, *dw32 = nullptr, *xin = nullptr, *xres = nullptr, *xout = nullptr; float *db = nullptr, *dsc = nullptr;
+        auto cleanup = [&]() { for (void* q : {dw, dw32, xin, xres, xout, (void*)db, (void*)dsc}) if (q) hipFree(q); };
+        hipError_t e = hipMalloc(&dw, wb);
+        if (e == hipSuccess && wb32) e = hipMalloc(&dw32, wb32);
+        if (e == hipSuccess) e = hipMalloc(&db, 4 * cp);
+        if (e == hipSuccess) e = hipMalloc(&dsc, 4 * cp);
+        if (e == hipSuccess) e = hipMalloc(&xin, nin * Cin * 4);
+        if (e == hipSuccess) e = hipMalloc(&xout, nout * Cout * 4);
+        if (e == hipSuccess && d_res) e = hipMalloc(&xres, nout * Cout * 4);
+        if (e == hipSuccess) e = hipMemcpy(dw, packed.data(), wb, hipMemcpyHostToDevice);
+        if (e == hipSuccess && wb32) e = hipMemcpy(dw32, p32.data(), wb32, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(db, bias.data(), 4 * cp, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(dsc, osc.data(), 4 * cp, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = launch_x3_split(reinterpret_cast<const float*>(d_in), xin, (long)nin, Cin, st);
+        if (e == hipSuccess && d_res) e = launch_x3_split(reinterpret_cast<const float*>(d_res), xres, (long)nout, Cout, st);
+        if (e == hipSuccess) {
+            ConvArgs a{};
+            a.in0 = xin; a.in0_ct = 2 * Cin; a.c0 = Cin; a.in0_bytes = (uint32_t)(nin * Cin * 4); a.in0_lo = Cin;
+            a.wgt = dw; a.wgt_bytes = (uint32_t)wb; a.bias = db; a.wgt32 = dw32; a.wgt32_bytes = (uint32_t)wb32; a.oscale = dsc; a.split = 1;
+            a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ho = Ho; a.Wo = Wo; a.Cin = Cin; a.Cout = Cout; a.k = k; a.s = s; a.act = act;
+            a.out = xout; a.out_ct = 2 * Cout; a.out_lo = Cout; a.out_bs = Ho * Wo;
+            if (d_res) { a.res = xres; a.res_ct = 2 * Cout; a.res_lo = Cout; }
+            e = launch_conv(c->prec, a, st);
+        }
+        if (e == hipSuccess) e = launch_x3_merge(xout, reinterpret_cast<float*>(d_out), (long)nout, Cout, st);
+        const hipError_t e2 = hipStreamSynchronize(st);
+        cleanup();
+        if (e != hipSuccess) return fail(c, CY_ERR_HIP, hipGetErrorString(e));
+        if (e2 != hipSuccess) return fail(c, CY_ERR_HIP, hipGetErrorString(e2));
+        return CY_OK;
+    }
     const size_t es = esize(c->prec);
     const size_t wb = packed_weight_bytes(c->prec, Cout, Cin, k);
     std::vector<char> packed(wb);
@@ -945,7 +1018,7 @@ int cy_preproc(cy_ctx* c, const float* d_mosaic, int MH, int MW, const int* h_ti
     int rc = fill_pre_args(c, d_mosaic, MH, MW, h_tiles, B, th, tw, cfg, d_status, a);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    a.out = d_netin; a.out_prec = c->prec; a.H = lb.H; a.W = lb.W; a.top = lb.top; a.left = lb.left;
+    a.out = d_netin; a.out_prec = io_prec(c->prec); a.H = lb.H; a.W = lb.W; a.top = lb.top; a.left = lb.left;
     a.new_h = lb.new_h; a.new_w = lb.new_w;
     const bool resize = (lb.new_h != th) || (lb.new_w != tw);
     if (resize && (size_t)B * 3 * th * tw > c->pre_scratch_elems) return fail(c, CY_ERR_ARG, "resize scratch too small");
@@ -975,7 +1048,7 @@ int cy_letterbox_pack(cy_ctx* c, const double* d_planes, int B, int h0, int w0, 
     if (lb.H > c->cfg.max_h || lb.W > c->cfg.max_w) return fail(c, CY_ERR_ARG, "letterboxed image exceeds max_h/max_w of the context");
     PreArgs a{};
     a.B = B; a.th = h0; a.tw = w0; a.scratch = const_cast<double*>(d_planes);
-    a.out = d_netin; a.out_prec = c->prec; a.H = lb.H; a.W = lb.W; a.top = lb.top; a.left = lb.left;
+    a.out = d_netin; a.out_prec = io_prec(c->prec); a.H = lb.H; a.W = lb.W; a.top = lb.top; a.left = lb.left;
     a.new_h = lb.new_h; a.new_w = lb.new_w;
     HIPCHK(c, launch_letterbox_pack(a, (hipStream_t)stream));
     return CY_OK;

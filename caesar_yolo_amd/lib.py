@@ -11,7 +11,8 @@ LIB_PATH = os.path.join(_HERE, "libcaesar_yolo_hip.so")
 CY_MAX_DET = 300
 CY_MAX_STAGES = 8
 OP_BKG, OP_SHIFT, OP_CLIP, OP_ZSCALE, OP_HISTEQ, OP_MINMAX = 1, 2, 3, 4, 5, 6
-F16, F32 = 0, 1
+F16, F32, F16X3 = 0, 1, 2
+PRECISIONS = {"fp16": F16, "f16": F16, "half": F16, "fp32": F32, "f32": F32, "float": F32, "fp16x3": F16X3, "f16x3": F16X3, "split": F16X3}
 
 EXPORTS = [
     "cy_create", "cy_destroy", "cy_last_error", "cy_load_weights", "cy_load_weights_mem", "cy_num_classes",

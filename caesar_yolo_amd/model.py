@@ -57,7 +57,14 @@ class HipDetector(object):
             raise L.CyError("no GPU visible: the HIP detector cannot run (no CPU fallback exists)")
         self.device = _dev_index(device)
         self.tdev = torch.device("cuda", self.device)
-        self.precision = L.F16 if precision in ("fp16", "f16", "half", L.F16) else L.F32
+        if isinstance(precision, str):
+            if precision.lower() not in L.PRECISIONS:
+                raise L.CyError("unknown precision %r (fp16 | fp16x3 | fp32)" % (precision,))
+            precision = L.PRECISIONS[precision.lower()]
+        if precision not in (L.F16, L.F32, L.F16X3):
+            raise L.CyError("unknown precision %r" % (precision,))
+        self.precision = precision
+        # dtype of the tensors that cross the C-ABI (network input, conv test entry): fp16 in the fp16 context, fp32 otherwise
         self.dtype = torch.float16 if self.precision == L.F16 else torch.float32
         self.max_batch = int(max_batch)
         m = (int(max_imgsz) + 31) // 32 * 32

@@ -23,7 +23,12 @@ extern "C" {
 typedef struct cy_ctx cy_ctx;
 
 enum cy_status { CY_OK = 0, CY_ERR_ARG = -1, CY_ERR_HIP = -2, CY_ERR_IO = -3, CY_ERR_STATE = -4, CY_ERR_UNSUPPORTED = -5 };
-enum cy_precision { CY_F16 = 0, CY_F32 = 1 };   /* CY_F16: fp16 operands, fp32 accumulate (fast); CY_F32: exact fp32 (parity) */
+/* CY_F16: fp16 operands, fp32 accumulate (fast); CY_F32: exact fp32 FMA chains on v_mfma_f32_16x16x4_f32 (reference arithmetic,
+ * slow); CY_F16X3: the fast parity context -- activations and weights carried as fp16 high + low halves (22 significand bits),
+ * every product evaluated as hi*hi + lo*hi + hi*lo on the fp16 matrix cores with fp32 accumulation (3x the K of CY_F16).
+ * Buffers the caller hands to cy_forward / cy_preproc / cy_letterbox_pack / cy_conv_bn_silu are fp32 in the CY_F32 and CY_F16X3
+ * contexts and fp16 in CY_F16. */
+enum cy_precision { CY_F16 = 0, CY_F32 = 1, CY_F16X3 = 2 };
 
 #define CY_MAX_DET 300        /* ultralytics max_det */
 #define CY_DET_STRIDE 6       /* x1,y1,x2,y2,score,class */

@@ -61,7 +61,7 @@ def _compare_exact(got, ref):
     for g, r in zip(got, ref):
         assert g["class_id"] == r["class_id"] and g["class_name"] == r["class_name"] and g["name"] == r["name"]
         assert g["edge"] == r["edge"] and g["merged"] == r["merged"]
-        assert abs(g["score"] - r["score"]) <= 1e-4
+        assert abs(g["score"] - r["score"]) <= 2e-5
         for k in ("x1", "y1", "x2", "y2"):
             d = abs(g[k] - r[k])
             assert d <= 1.0, (g["name"], k, g[k], r[k])
@@ -76,19 +76,21 @@ EXPECT = {  # config: (tiles, rejected tiles, minimum sources in the oracle cata
 }
 
 
+@pytest.mark.parametrize("prec", ["fp32", "fp16x3"])
 @pytest.mark.parametrize("name", ["C2", "C3", "C5"])
-def test_config_catalog_fp32_matches_oracle(name, tmp_path):
+def test_config_catalog_fp32_matches_oracle(name, prec, tmp_path):
+    """Both parity contexts (exact fp32; fp16x3 = fp16 high + low halves on the tuned kernels) against the oracle catalog."""
     ref = CC.oracle_run(name)
     ntiles, nrej, min_src, min_merged = EXPECT[name]
     assert len(ref["grid"]) == ntiles and len(ref["skipped"]) == nrej
     assert len(ref["catalog"]) >= min_src, "oracle catalog too small to mean anything: %d" % len(ref["catalog"])
     assert sum(1 for s in ref["catalog"] if s["merged"]) >= min_merged
-    got, stats = _run_sfinder(tmp_path, name, "fp32")
+    got, stats = _run_sfinder(tmp_path, name, prec)
     assert stats["tiles"] == ntiles and stats["skipped"] == nrej
     assert stats["per_tile_detections"] == sum(len(d[1]) for d in ref["dets"] if d is not None)
     off = _compare_exact(got, ref["catalog"])
-    print("%s fp32: %d sources (%d merged across tiles), %d of %d integer coordinates differ by one" % (
-        name, len(got), sum(1 for s in got if s["merged"]), off, 4 * len(got)))
+    print("%s %s: %d sources (%d merged across tiles), %d of %d integer coordinates differ by one" % (
+        name, prec, len(got), sum(1 for s in got if s["merged"]), off, 4 * len(got)))
     assert off <= max(2, len(got) // 25)
 
 

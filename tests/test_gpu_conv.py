@@ -1,7 +1,8 @@
 """Kernel-level parity: the fused conv implicit-GEMM (csrc/conv_igemm.hip) against a plain PyTorch fp32 reference of
 the same op (F.conv2d + bias + SiLU + residual), through the C-ABI entry cy_conv_bn_silu.
 Tolerances: f32 path (exact-fp32 MFMA) 2e-5 relative to the output scale; f16 path (fp16 operands, fp32 accumulate)
-is compared on fp16-rounded inputs/weights with 4e-3 relative to the output scale (one fp16 rounding of the result)."""
+is compared on fp16-rounded inputs/weights with 4e-3 relative to the output scale (one fp16 rounding of the result);
+fp16x3 path (fp16 high + low halves, three MFMA passes, fp32 accumulate): fp32 inputs, the f32 tolerance 2e-5."""
 import numpy as np
 import pytest
 import torch
@@ -48,7 +49,7 @@ CASES = [  # B, H, W, Cin, Cout, k, s, act, residual
 
 # fp16 twice: with the default batch-invariant kernel selection (thresholds see a 256-tile batch) and with the selection
 # that sees the real (small) batch of the case: between them every kernel variant runs
-@pytest.mark.parametrize("prec,inv", [("fp32", "1"), ("fp16", "1"), ("fp16", "0")])
+@pytest.mark.parametrize("prec,inv", [("fp32", "1"), ("fp16", "1"), ("fp16", "0"), ("fp16x3", "1")])
 @pytest.mark.parametrize("case", CASES)
 def test_conv_bn_silu(prec, inv, case, monkeypatch):
     monkeypatch.setenv("CY_BATCH_INVARIANT", inv)
@@ -77,7 +78,7 @@ def test_conv_bn_silu(prec, inv, case, monkeypatch):
     got = out.float().cpu().permute(0, 3, 1, 2)
     assert got.shape == y.shape
     scale = float(y.abs().max())
-    tol = (2e-5 if prec == "fp32" else 4e-3) * max(scale, 1.0)
+    tol = (4e-3 if prec == "fp16" else 2e-5) * max(scale, 1.0)
     err = float((got - y).abs().max())
     assert err <= tol, "max abs err %.3e > %.3e (scale %.2f)" % (err, tol, scale)
 
@@ -103,6 +104,47 @@ def test_two_group_and_ring_kernels_are_repeatable(case):
     first = det.conv_bn_silu(xd, w1, b, 1, 1, True, rd)
     for _ in range(20):
         assert torch.equal(first, det.conv_bn_silu(xd, w1, b, 1, 1, True, rd))
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_conv_random_geometry_fp16x3(seed):
+    """The same seeded random geometries through the fp16x3 context (three-pass K walk of the wide / pixels-direct / generic
+    kernels, scaled weights, high / low output halves) against F.conv2d in float64: 4e-6 of the output scale."""
+    rng = np.random.default_rng(1000 + seed)
+    k = int(rng.choice([1, 3]))
+    s = int(rng.choice([1, 2])) if k == 3 else 1
+    Cin = int(rng.choice([64, 128, 192, 256, 320]))
+    Cout = int(rng.choice([40, 64, 96, 128, 160, 192, 256, 320]))
+    H = int(rng.choice([15, 16, 31, 32, 33, 48, 64]))
+    Wd = int(rng.choice([16, 30, 32, 34, 62, 64, 96]))
+    B = int(rng.choice([1, 3, 8, 24]))
+    act = bool(rng.integers(0, 2))
+    use_res = bool(rng.integers(0, 2))
+    det = detector("fp16x3")
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn((B, Cin, H, Wd), generator=g)
+    w = torch.randn((Cout, Cin, k, k), generator=g) / (Cin * k * k) ** 0.5
+    w[0] *= 1e-3                                          # rows of very different magnitude: the per-channel weight scale
+    w[-1] *= 50.0
+    b = torch.randn((Cout,), generator=g) * 0.1
+    y = F.conv2d(x.double(), w.double(), b.double(), stride=s, padding=k // 2)
+    if act:
+        y = F.silu(y)
+    res = None
+    if use_res:
+        res = torch.randn(y.shape, generator=g)
+        y = y + res.double()
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    rd = res.permute(0, 2, 3, 1).contiguous().cuda() if use_res else None
+    out = det.conv_bn_silu(xd, w.numpy(), b.numpy(), k, s, act, rd)
+    torch.cuda.synchronize()
+    got = out.double().cpu().permute(0, 3, 1, 2)
+    assert got.shape == y.shape
+    scale = max(float(y.abs().max()), 1.0)
+    err = float((got - y).abs().max())
+    print("fp16x3 B%d %dx%d %d->%d k%d s%d: max abs err %.3e of scale %.2f (%.2e)" % (B, H, Wd, Cin, Cout, k, s, err, scale, err / scale))
+    assert err <= 4e-6 * scale, "B%d %dx%d %d->%d k%d s%d act%d res%d: max abs err %.3e (scale %.2f)" % (
+        B, H, Wd, Cin, Cout, k, s, act, use_res, err, scale)
 
 
 @pytest.mark.parametrize("seed", list(range(24)))

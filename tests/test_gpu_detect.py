@@ -76,16 +76,24 @@ def test_iou_merge_matches_reference_golden():
         assert np.array_equal(o[:, 5].astype(np.int32), g[k + "/out_cls"]), k
 
 
+# measured on MI355X (printed by the test): fp32 context <= 2.1e-3 px / 7e-6 score.  The asserted bounds are those figures with a
+# factor ~2.5 of head-room, NOT the 1e-4 * max(H, W) (0.064 px) the normalised north-star tolerance would allow.
+E2E_BOX_PX, E2E_SCORE = 5e-3, 2e-5
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16x3"])
 @pytest.mark.parametrize("name,imgsz", [("big512", 512), ("galaxy", 640), ("syn192", 192)])
-def test_model_call_end_to_end_fp32(name, imgsz):
-    """The `model(image, imgsz=, conf=, iou=)` surface of caesar_yolo/evaluation.py:181-193 on the f32 context."""
+def test_model_call_end_to_end_fp32(name, imgsz, prec):
+    """The `model(image, imgsz=, conf=, iou=)` surface of caesar_yolo/evaluation.py:181-193 on the two parity contexts (exact
+    fp32, and fp16x3 = fp16 high + low halves on the tuned kernels): same boxes in the same order, classes equal, boxes within
+    5e-3 px, scores within 2e-5."""
     from caesar_yolo_amd.model import YOLO
     from gpu_common import seeded_weights
     conf, iou = 0.7, 0.5
     img = _prep(name)
     m = oracle_model()
     d_ref, a_ref, raw, pred_ref = m.predict_raw(img, imgsz, conf, iou)
-    y = YOLO(seeded_weights()[0], precision="fp32", max_batch=2, max_imgsz=640, device=0)
+    y = YOLO(seeded_weights()[0], precision=prec, max_batch=2, max_imgsz=640, device=0)
     assert y.names == m.names
     r = y(img, device="cuda:0", imgsz=imgsz, conf=conf, iou=iou, save=False, visualize=False, show=False)[0]
     xyxy, cf, cl = r.boxes.xyxy.cpu().numpy(), r.boxes.conf.cpu().numpy(), r.boxes.cls.cpu().numpy()
@@ -98,9 +106,9 @@ def test_model_call_end_to_end_fp32(name, imgsz):
         H, W = [s * 8 for s in m.net.level_shapes[0]]
         berr = float(np.abs(xyxy - d_ref[:, :4].numpy()).max()) if len(cf) else 0.0
         serr = float(np.abs(cf - d_ref[:, 4].numpy()).max()) if len(cf) else 0.0
-        print("end-to-end fp32 %s@%d: %d boxes, max |dbox| = %.3e px (%.2e normalised), max |dscore| = %.3e"
-              % (name, imgsz, len(cf), berr, berr / max(H, W), serr))
-        assert berr <= 1e-4 * max(H, W)
-        assert serr <= 1e-4
+        print("end-to-end %s %s@%d: %d boxes, max |dbox| = %.3e px (%.2e normalised), max |dscore| = %.3e"
+              % (prec, name, imgsz, len(cf), berr, berr / max(H, W), serr))
+        assert berr <= E2E_BOX_PX
+        assert serr <= E2E_SCORE
     else:
         pytest.skip("%d candidates within 1e-5 of the confidence threshold" % near)

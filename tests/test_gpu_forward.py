@@ -37,7 +37,7 @@ TAPS = ["model.0", "model.1", "model.2.cv1", "model.2.m.2.cv1", "model.12.m.0.cv
 
 
 @pytest.mark.parametrize("prec,tol_raw,tol_tap,env", [
-    ("fp32", 2e-4, 1e-4, {}), ("fp16", 6e-2, 3e-2, {}),
+    ("fp32", 2e-4, 1e-4, {}), ("fp16x3", 2e-4, 1e-4, {}), ("fp16", 6e-2, 3e-2, {}),
     # the kernels that only take over at benchmark-sized batches, forced on this small one: pixels-direct 1x1 (incl. the
     # upsample+concat inputs of layers 12/15), and with it off, the 256x128 ring kernel
     ("fp16", 6e-2, 3e-2, {"CY_DIRECT_MIN_BLOCKS": "1"}), ("fp16", 6e-2, 3e-2, {"CY_DIRECT_MIN_BLOCKS": "-1"}),
@@ -74,9 +74,10 @@ def test_forward_matches_oracle(prec, tol_raw, tol_tap, env, monkeypatch):
     assert err <= tol_raw * max(1.0, float(raw.abs().max())), "raw head output: max abs err %.3e" % err
 
 
-def test_forward_ragged_letterboxed_shape_fp32():
+@pytest.mark.parametrize("prec", ["fp32", "fp16x3"])
+def test_forward_ragged_letterboxed_shape_fp32(prec):
     """394-wide edge tiles of the 16k mosaic letterbox to 416x512: non-square grids, 3 batch entries."""
-    det = detector("fp32")
+    det = detector(prec)
     base = _tile("big512")
     imgs = [base[:512, :394].copy(), base[:512, 100:494].copy(), base[:512, 118:512].copy()]
     x, raw, _ = _oracle_forward(imgs, 512)
@@ -116,7 +117,7 @@ def test_other_scales_fp32(scale, nc):
     if not os.path.exists(path):
         W.make_seeded_file(path, scale, nc)
     sc, names, wd, _ = W.read_cyw(path)
-    for prec, tol in (("fp32", 3e-4), ("fp16", 8e-2)):
+    for prec, tol in (("fp32", 3e-4), ("fp16x3", 3e-4), ("fp16", 8e-2)):
         det = HipDetector(path, device=0, precision=prec, max_batch=2, max_imgsz=256)
         om = Y.OracleYOLO(wd, names, sc)
         imgs = [_tile("big512", 192, 256), _tile("big512", 192, 256)[:, ::-1].copy()]
@@ -147,6 +148,23 @@ def test_batch_invariant_mode_is_bit_exact(monkeypatch):
         assert torch.equal(p1[0], p4[i]), "tile %d differs between batch 1 and batch 4" % i
     p3 = det.forward(xin[1:4].contiguous()).cpu()
     assert torch.equal(p3, p4[1:4])
+
+
+def test_fp16x3_results_do_not_depend_on_the_batch():
+    """fp16x3 context: the kernel of a layer is chosen from its geometry alone, so a tile's head output is bit-identical alone
+    and in any batch (catalogs independent of world size / batch split in the parity mode as well)."""
+    det = detector("fp16x3")
+    base = _tile("big512", 256, 256)
+    imgs = [base, base[::-1].copy(), base[:, ::-1].copy(), base[::-1, ::-1].copy()]
+    x, raw, _ = _oracle_forward(imgs, 256)
+    xin = netin_from_chw(x, det.dtype)
+    p4 = det.forward(xin).cpu()
+    err = float((p4 - raw).abs().max())
+    print("fp16x3 raw head output vs oracle: max abs err %.3e (scale %.2f)" % (err, float(raw.abs().max())))
+    assert err <= 2e-4 * max(1.0, float(raw.abs().max()))
+    for i in range(4):
+        p1 = det.forward(xin[i:i + 1].contiguous()).cpu()
+        assert torch.equal(p1[0], p4[i]), "tile %d differs between batch 1 and batch 4" % i
 
 
 @pytest.mark.parametrize("shape", [(3, 160, 192), (20, 256, 256), (1, 512, 512), (5, 96, 416)])

@@ -47,7 +47,7 @@ def _compare_sources(got, ref):
     for g, r in zip(got, ref):
         assert g["class_id"] == r["class_id"] and g["class_name"] == r["class_name"]
         assert g["edge"] == r["edge"] and g.get("merged") == r.get("merged") and g["name"] == r["name"]
-        assert abs(g["score"] - r["score"]) <= 1e-4
+        assert abs(g["score"] - r["score"]) <= 2e-5
         for k in ("x1", "y1", "x2", "y2"):
             d = abs(g[k] - r[k])
             assert d <= 1.0, (k, g[k], r[k])
@@ -142,9 +142,9 @@ def test_predict_tiles_batched_entry():
         assert len(r.boxes.conf) == len(ks)
         ndet += len(ks)
         if len(ks):
-            np.testing.assert_allclose(r.boxes.conf.cpu().numpy(), ks, atol=1e-4)
+            np.testing.assert_allclose(r.boxes.conf.cpu().numpy(), ks, atol=2e-5)
             np.testing.assert_array_equal(r.boxes.cls.cpu().numpy().astype(int), np.asarray(kc).astype(int))
-            np.testing.assert_allclose(r.boxes.xyxy.cpu().numpy(), kb, atol=256 * 1e-4)
+            np.testing.assert_allclose(r.boxes.xyxy.cpu().numpy(), kb, atol=5e-3)       # pixels
     assert ndet >= 8
     with pytest.raises(ValueError):
         model.predict_tiles(mosaic, [(0, 256, 0, 256), (0, 200, 0, 256)], cfg, imgsz=256)
