@@ -54,6 +54,9 @@ def parse_args(argv=None):
     ap.add_argument("--size", type=int, default=0, help="mosaic edge (default: the workload's)")
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--precision", default="fp16", help="context precision of the headline run: fp16 | fp16x3 | fp32")
+    ap.add_argument("--parity-steps", type=int, default=-1,
+                    help="timed passes of the same workload in the fp16x3 parity context after the headline run (reported as "
+                         "`parity_mode`; default: 1 when the headline is fp16, else 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-launch hipEvents in the timed region")
     ap.add_argument("--no-exclusive", action="store_true", help="skip the extra forward passes after the timed region that time the dominant kernel alone (roofline.achieved_exclusive)")
@@ -151,34 +154,65 @@ def cpu_baseline(mosaic_host, grid, names_w, wl, budget_s=24.0, max_tiles=48):
             "runs": runs}
 
 
-def pmc_traffic(kernel_label):
-    """HBM bytes per launch of the dominant kernel from the tracked rocprofv3 PMC passes (profiles/*_hbm_traffic.json,
-    collected by tools/collect_profiles.sh on this same command line) -> (bytes or None, file it came from)."""
-    import glob
-
-    def family(n):
-        n = n.replace(" ", "")
-        if "conv3x3_wide_kernel" in n:                     # <TAIL, WN>: the 128-channel (WN=2) and the 64-channel (WN=1) variant
-            return "conv3x3_wide_kernel/64" if (",1>" in n or "WN=1" in n) else "conv3x3_wide_kernel/128"
-        for fam in ("conv3x3_halo2_kernel", "conv3x3_halo_kernel", "conv3x3_pp_kernel", "conv3x3_c64_kernel", "stem_mfma_kernel"):
-            if fam in n:
-                return fam
-        if "conv1x1_direct_kernel" in n:
-            return "conv1x1_direct_kernel<4" if ("<4,2" in n or "ILi4ELi2E" in n) else "conv1x1_direct_kernel<2"
-        if "conv_igemm_kernel" in n:
-            if "<4,2,4,3>" in n or "Li4ELi2ELi4ELi3E" in n:
-                return "conv_igemm_kernel<4,2,4,3>"
-            return "conv_igemm_kernel<2,2,4>" if ("<2,2,4>" in n or "Li2ELi2ELi4E" in n) else "conv_igemm_kernel<4,1,2>"
+def kernel_family(n):
+    """rocprofv3 kernel name (demangled `conv3x3_wide_kernel<true, 2, false, 2, false>` or mangled `_ZN2cy...ILb1ELi2E...`) or one
+    of the variant labels of the library's profile summary -> the key both agree on, or None."""
+    import re
+    n = n.replace(" ", "")
+    base = None
+    for b in ("conv3x3_wide_kernel", "conv1x1_direct_kernel", "conv_igemm_kernel", "conv3x3_halo2_kernel", "conv3x3_halo_kernel",
+              "conv3x3_pp_kernel", "conv3x3_c64_kernel", "stem_down2_kernel", "stem_down_kernel", "stem_mfma_kernel", "pool5_kernel"):
+        if b in n:
+            base = b
+            break
+    if base is None:
         return None
-    want, best, src = family(kernel_label), None, None
+    tail = n.split(base, 1)[1]
+    if tail.startswith("<") and ">" in tail and "=" not in tail.split(">")[0]:
+        targs = [a for a in tail[1:].split(">")[0].split(",") if a]
+        vals = [{"true": 1, "false": 0}.get(a, int(a) if a.lstrip("-").isdigit() else None) for a in targs]
+        if None in vals:
+            vals = None                             # e.g. the label "conv3x3_wide_kernel<dual> ..."
+    elif tail.startswith("I"):                      # mangled template arguments: Lb1E / Li4E / DF16_ / f
+        vals = [int(v) for v in re.findall(r"L[bi](\d+)E", tail.split("EEv")[0])]
+    else:
+        vals = None                                 # a variant label of the profile summary
+    if base == "conv3x3_wide_kernel":
+        if vals is None:
+            return base + ("/64" if "WN=1" in tail else "/dual" if "dual" in tail else "/128")
+        wn, dual, split = (vals + [0, 0, 0, 0, 0])[1], (vals + [0] * 5)[2], (vals + [0] * 5)[4]
+        return base + ("/64" if wn == 1 else "/dual" if dual else "/128") + ("/x3" if split else "")
+    if base == "conv1x1_direct_kernel":
+        if vals is None:
+            return base + ("/256" if tail.startswith("<4,2>") else "/128")
+        return base + ("/256" if vals[0] == 4 else "/128") + ("/x3" if (vals + [0] * 5)[4] else "")
+    if base == "conv_igemm_kernel":
+        if vals is None:
+            vals = [int(v) for v in re.findall(r"\d+", tail.split(">")[0])]
+        v = [x for x in vals if x is not None]
+        return base + "<%s>" % ",".join(str(x) for x in v[:3]) + (",3" if len(v) > 3 and v[3] == 3 else "")
+    return base
+
+
+def pmc_traffic(kernel_label):
+    """HBM bytes per launch of a kernel family from the tracked rocprofv3 PMC passes (profiles/*_hbm_traffic.json, collected by
+    tools/collect_profiles.sh on this same command line; the newest file that knows the family wins; several template
+    instances of one family -- e.g. the 1x1 and the strided-3x3 form of the pixels-direct kernel -- are averaged by launches)
+    -> (bytes or None, file it came from)."""
+    import glob
+    want, best, src = kernel_family(kernel_label), None, None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json"))):
         try:
             t = json.load(open(f))
         except Exception:
             continue
+        tot = n = 0.0
         for name, v in t.items():
-            if want and family(name) == want:
-                best, src = v["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
+            if want and kernel_family(name) == want:
+                tot += v["hbm_bytes_per_launch"] * v["launches"]
+                n += v["launches"]
+        if n:
+            best, src = tot / n, os.path.relpath(f, ROOT)
     return best, src
 
 
@@ -249,32 +283,37 @@ def run_rank(args):
     from caesar_yolo_amd.lib import letterbox as utils_letterbox
 
     size = args.size or wl["size"]
-    batch = args.batch or wl["batch"]
+    # tiles per launch: 256 in the fp16 context; the fp32 / fp16x3 contexts hold 4 bytes per activation value and the largest
+    # tensor of a launch must stay below the 4 GiB a buffer resource can address -> 128
+    batch = args.batch or (wl["batch"] if args.precision == "fp16" else min(wl["batch"], 128))
     t_setup = time.time()
     # rank 0 writes the seeded weight file and the synthetic FITS; the others reuse both
     import tempfile
     fits_path = os.path.join(tempfile.gettempdir(), "cy_bench_%s_%d_%d.fits" % (args.config, size, os.getuid()))
     mosaic_host = None
-    model = None
     if rank == 0:
-        model = YOLO("seeded:l:5", precision=args.precision, max_batch=batch, max_imgsz=wl["imgsz"], device=local)
+        YOLO("seeded:l:5")             # resolves (= writes on first use) the seeded weight file before the other ranks look for it
         mosaic_host = synth.make_mosaic(size, seed=wl["seed"])
         utils.write_fits_image(fits_path, mosaic_host, synth.FITS_CARDS)
     if world > 1:
         dist.barrier()
-    if model is None:
-        model = YOLO("seeded:l:5", precision=args.precision, max_batch=batch, max_imgsz=wl["imgsz"], device=local)
-    det = model.engine(local)
     grid = utils.generate_tiles(0, size - 1, 0, size - 1, wl["tile"], wl["tile"], wl["step"], wl["step"])
     cfg = CP.device_pipeline(wl["pre"]).program()
-    # ingest, timed: FITS header + memory map -> this rank's regions -> H2D -> byte swap / non-finite -> 0 on device
-    torch.cuda.synchronize()
-    t_in = time.time()
-    data, _hdr = utils.read_fits_image(fits_path)
-    src = MosaicSource(data, big_endian=True)
-    eng = TileEngine(det, src, grid, cfg, wl["imgsz"], 0.7, 0.5, 0.3, 0.8, rank, world, batch)
-    torch.cuda.synchronize()
-    ms_ingest = 1000.0 * (time.time() - t_in)
+
+    def make_engine(precision, nbatch):
+        """context + this rank's share of the mosaic resident in HBM -> (model, detector, engine, source, ingest ms)"""
+        m = YOLO("seeded:l:5", precision=precision, max_batch=nbatch, max_imgsz=wl["imgsz"], device=local)
+        d = m.engine(local)
+        # ingest, timed: FITS header + memory map -> this rank's regions -> H2D -> byte swap / non-finite -> 0 on device
+        torch.cuda.synchronize()
+        t_in = time.time()
+        data, _hdr = utils.read_fits_image(fits_path)
+        sr = MosaicSource(data, big_endian=True)
+        en = TileEngine(d, sr, grid, cfg, wl["imgsz"], 0.7, 0.5, 0.3, 0.8, rank, world, nbatch)
+        torch.cuda.synchronize()
+        return m, d, en, sr, 1000.0 * (time.time() - t_in)
+
+    model, det, eng, src, ms_ingest = make_engine(args.precision, batch)
     # the same ingest once more: the first one also pays for the allocations (pinned staging buffers, the device buffer of the
     # band) that a process ingesting one mosaic after the other pays once
     t_in = time.time()
@@ -289,17 +328,18 @@ def run_rank(args):
 
     tsplit = {"local": 0.0, "gather": 0.0, "merge": 0.0}
 
-    def step():
+    def step(e=None):
+        e = e or eng
         t0 = time.time()
-        eng.run_local()
+        e.run_local()
         torch.cuda.synchronize()
         t1 = time.time()
-        eng.gather()
+        e.gather()
         torch.cuda.synchronize()
         t2 = time.time()
         cat = stats = None
         if rank == 0:
-            cat, stats = eng.merged_records()         # final catalog records in host memory (D2H synchronises)
+            cat, stats = e.merged_records()           # final catalog records in host memory (D2H synchronises)
         t3 = time.time()
         tsplit["local"] += t1 - t0; tsplit["gather"] += t2 - t1; tsplit["merge"] += t3 - t2
         return cat, stats
@@ -352,9 +392,51 @@ def run_rank(args):
         det.profile(False)
         del x
 
+    # ---- the same workload in the parity context (fp16x3: the mode that meets the north star's parity bar), same timing protocol
+    parity = None
+    psteps = args.parity_steps if args.parity_steps >= 0 else (1 if args.precision == "fp16" else 0)
+    if psteps > 0:
+        del eng
+        pb = min(batch, 128)                                   # 4 bytes per activation value: 128 tiles keep every tensor below 4 GiB
+        pmodel, pdet, peng, psrc, _ = make_engine("fp16x3", pb)
+        step(peng)                                             # warm-up pass
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        tp0 = time.time()
+        for _ in range(psteps):
+            pcat, pstats = step(peng)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        pdt = time.time() - tp0
+        if world > 1:
+            cpu = dist.get_backend() != "nccl"
+            tmax = torch.tensor([pdt], dtype=torch.float64, device="cpu" if cpu else "cuda")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            pdt = float(tmax.item())
+        if rank == 0:
+            parity = {"dtype": "fp16x3", "precision": "fp16 high + low halves (22 significand bits) for activations and weights, three MFMA passes "
+                                                      "(lo*hi, hi*lo, hi*hi), fp32 accumulate: the context tests/test_gpu_configs.py holds to the "
+                                                      "north star's parity bar (kept-anchor sets identical, boxes 1e-4, scores 2e-5 vs the oracle)",
+                      "value": len(grid) * psteps / pdt, "unit": "tiles/s", "ms_per_step": 1000.0 * pdt / psteps, "steps": psteps, "warmup": 1,
+                      "tile_batch": pb, "sources_in_catalog": len(pcat), "per_tile_detections": pstats["per_tile_detections"],
+                      "vs_fp16_headline": None}
+        del peng, psrc
+        pdet.close()
+
     if rank == 0:
         ntiles = len(grid)
         value = ntiles * args.steps / dt
+        lbf = utils_letterbox(wl["tile"], wl["tile"], wl["imgsz"])
+        flops_pass = 0.0
+        for t in grid:
+            lbt = utils_letterbox(t[3] - t[2], t[1] - t[0], wl["imgsz"])
+            flops_pass += wl["flop"] * (lbt.H * lbt.W) / float(lbf.H * lbf.W)
+        if parity:
+            parity["vs_fp16_headline"] = parity["value"] / value if args.precision == "fp16" else None
+            parity["conv_stack_mfma_frac_whole_job"] = 3.0 * flops_pass * parity["value"] / ntiles / 1e12 / (PEAK_FP16_DENSE_TFLOPS * world)
+            parity["conv_stack_mfma_frac_note"] = "MFMA work of the context = 3 x the algorithmic conv FLOPs (three fp16 passes per product)"
         n_gpus = dist.get_world_size() if world > 1 else 1        # the ranks the communicator actually has
         ms_step = 1000.0 * dt / args.steps
         ms_in = max(r[2] for r in per_rank) if per_rank else ms_ingest
@@ -373,7 +455,10 @@ def run_rank(args):
                        "per_tile_detections": stats["per_tile_detections"],
                        "degenerate_boxes_dropped": stats.get("degenerate_boxes", 0),
                        "candidate_overflow_tiles": stats.get("cand_overflow_tiles", 0)},
-            "conv_stack_mfma_frac_whole_job": value * wl["flop"] / 1e12 / (PEAK_FP16_DENSE_TFLOPS * world),
+            # algorithmic conv FLOPs of the pass: per tile, the full-tile figure x (letterboxed pixels / full letterboxed pixels) -- the
+            # network is fully convolutional, so the 79 ragged tiles of the 16k grid count with their own (smaller) maps
+            "conv_stack_mfma_frac_whole_job": flops_pass * args.steps / dt / 1e12 / (PEAK_FP16_DENSE_TFLOPS * world),
+            "conv_flops_per_pass": flops_pass,
             "step_split_ms_rank0": {k: 1000.0 * v / args.steps for k, v in tsplit.items()},
             # host-inclusive view (never `value`): FITS memory map -> H2D of this rank's regions -> on-device byte swap
             "ms_ingest": ms_in, "ingest_mb_rank0": src.bytes_uploaded / 1e6,
@@ -381,6 +466,8 @@ def run_rank(args):
             "ms_ingest_warm_rank0": ms_ingest_warm,     # second ingest of the same file in this process (buffers already allocated)
             "tiles_per_s_incl_ingest_warm": ntiles / ((ms_step + ms_ingest_warm) * 1e-3) if world == 1 else None,
         }
+        if parity:
+            out["parity_mode"] = parity
         if per_rank:
             out["per_rank"] = [{"rank": i, "tiles": int(r[3]), "local_ms": 1000.0 * r[0] / args.steps,
                                 "gather_ms": 1000.0 * r[1] / args.steps, "ingest_ms": r[2], "mosaic_mb": r[4] / 1e6}
@@ -409,6 +496,22 @@ def run_rank(args):
                                              + ("; batches of 64..239 tiles run their forward as two concurrent half-batches on two streams, so the "
                                                 "launches timed here overlap each other and `achieved` understates the kernel's exclusive rate by up to 2x"
                                                 if 64 <= batch < 240 else "")}
+            # the largest HBM-bound kernel of the forward pass: bytes per launch from the tracked PMC passes x its launches / its event time
+            hb = None
+            for q in prof:
+                fam = kernel_family(q["kernel"]) or ""
+                if fam in ("conv3x3_c64_kernel", "conv1x1_direct_kernel/128", "stem_down2_kernel", "stem_down_kernel") and q["ms"] > 0:
+                    byt, bsrc = pmc_traffic(q["kernel"])
+                    if byt and (hb is None or q["ms"] > hb[0]["ms"]):
+                        hb = (q, byt, bsrc)
+            if hb:
+                q, byt, bsrc = hb
+                tbs = byt * q["launches"] / (q["ms"] * 1e-3) / 1e12
+                out["roofline_hbm"] = {"kernel": q["kernel"], "bound": "hbm", "achieved": tbs, "peak": 8.0, "unit": "TB/s", "frac": tbs / 8.0,
+                                       "traffic": byt, "launches": q["launches"], "avg_launch_ms": q["ms"] / q["launches"],
+                                       "traffic_source": "%s (2 x FETCH_SIZE + WRITE_SIZE per launch, separate rocprofv3 --pmc passes; launch times: "
+                                                         "hipEvents of this run, full batches)" % bsrc,
+                                       "TFLOP/s": q["flops"] / (q["ms"] * 1e-3) / 1e12}
             tot_ms = sum(p["ms"] for p in prof)
             out["forward_kernels"] = [{"kernel": p["kernel"], "ms_total": p["ms"], "launches": p["launches"],
                                        "TFLOP/s": (p["flops"] / (p["ms"] * 1e-3) / 1e12) if p["ms"] > 0 else 0.0,

@@ -125,11 +125,14 @@ __device__ __forceinline__ void store_split1(f16* dst, int lo_off, float v) {
     const f16 h = (f16)v;
     dst[0] = h; dst[lo_off] = (f16)(v - (float)h);
 }
-// virtual K chunk of the fp16x3 passes [x_hi | x_lo | x_hi] -> physical chunk; lo = 1 in the middle pass
+// virtual K chunk of the fp16x3 passes [x_lo | x_hi | x_hi] (against weights [w_hi | w_lo | w_hi]) -> physical chunk; lo = 1 in the
+// first pass.  The two small cross terms come FIRST: the fp32 accumulator of the MFMA rounds at every step by an amount relative
+// to its current magnitude, so they are summed while it is still ~2^-11 of the final value (their rounding is then negligible)
+// and the x_hi * w_hi chain runs last, exactly as long as in the fp16 context.
 __device__ __forceinline__ int x3_chunk(int v, int per_pass, int& lo) {
-    lo = 0;
+    lo = v < per_pass;
     if (v >= 2 * per_pass) return v - 2 * per_pass;
-    if (v >= per_pass) { lo = 1; return v - per_pass; }
+    if (v >= per_pass) return v - per_pass;
     return v;
 }
 
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_ige
     const int m0 = (id / ntn) * BM, n0 = (id % ntn) * BN;
     const int taps = a.k * a.k, cpad = pad128(a.Cout);
     const int pchunks = (a.Cin + BKE - 1) / BKE;             // K chunks of one pass over the input channels
-    const int cchunks = SPLIT ? 3 * pchunks : pchunks;       // fp16x3: three passes (x_hi w_hi, x_lo w_hi, x_hi w_lo)
+    const int cchunks = SPLIT ? 3 * pchunks : pchunks;       // fp16x3: three passes (x_lo w_hi, x_hi w_lo, x_hi w_hi)
     const int nslab = taps * cchunks;
 
     const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in0), 0, a.in0_bytes, 0x00020000);
@@ -1323,8 +1326,8 @@ static hipError_t launch_halo2(const ConvArgs& a, hipStream_t s) {
 // TWO consecutive images, each with its own left/right halo column (patch rows of 36 instead of 34 pixels).
 template <bool TAIL, int WN, bool DUAL = false, int TPS = 2, bool SPLIT = false>
 __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
-    // SPLIT (fp16x3 context): three passes over the input channels -- halo slabs of [x_hi | x_lo | x_hi] against the weight
-    // slabs [w_hi | w_hi | w_lo] of the packed copy, i.e. the same stage loop over 3x the slab pairs; scaled / split epilogue
+    // SPLIT (fp16x3 context): three passes over the input channels -- halo slabs of [x_lo | x_hi | x_hi] against the weight
+    // slabs [w_hi | w_lo | w_hi] of the packed copy, i.e. the same stage loop over 3x the slab pairs; scaled / split epilogue
     // TPS = taps per stage (between two barriers): 2, or 3 (WN = 2 only: six stages of 96 MFMAs per slab pair, 152 KiB of LDS)
     static_assert(TPS == 2 || (TPS == 3 && WN == 2), "three taps per stage: 128-channel variant only");
     constexpr int NST = 18 / TPS;
@@ -1376,7 +1379,7 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
     }
     auto dma_patch = [&](int buf, int slab) {               // slab: 32-channel slab index
         unsigned so = (unsigned)slab * 64u;
-        if constexpr (SPLIT) {                               // virtual slab -> physical slab (+ the offset of the low halves in the middle pass)
+        if constexpr (SPLIT) {                               // virtual slab -> physical slab (+ the offset of the low halves in the first pass)
             int lo;
             so = (unsigned)x3_chunk(slab, 2 * ppairs, lo) * 64u;
             if (lo) so += (unsigned)a.in0_lo * 2u;
@@ -1725,8 +1728,8 @@ static hipError_t launch_wide(const ConvArgs& a, hipStream_t s) {
 // Also handles the two-segment input (nearest-x2 upsample + concat) of layers 12 and 15: per-lane addresses anyway.
 template <int NB, int MI, int RING, bool K3, bool SPLIT = false>
 __global__ __launch_bounds__(512, (NB * MI <= 4 && RING == 2) ? 2 : 1) void conv1x1_direct_kernel(const ConvArgs a) {
-    // SPLIT (fp16x3 context): three passes over the K chunks -- pixels [x_hi | x_lo | x_hi] (the low halves a.in*_lo halves behind
-    // the high ones) against the packed weight chunks [w_hi | w_hi | w_lo]; scaled / split epilogue
+    // SPLIT (fp16x3 context): three passes over the K chunks -- pixels [x_lo | x_hi | x_hi] (the low halves a.in*_lo halves behind
+    // the high ones) against the packed weight chunks [w_hi | w_lo | w_hi]; scaled / split epilogue
     constexpr int NW = 8, BN = 64 * NB, BM = NW * MI * 16, W_BYTES = BN * 128, DIST = RING - 1;
     constexpr int WPW = BN / 8 / NW, APW = 2 * MI, PER = WPW + APW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2203,7 +2206,7 @@ void pack_weights(Precision p, const float* W, int cout, int cin, int k, void* d
 // fp16x3 context.  Per output channel n the filter is scaled by 2^e(n) so that its largest weight lies in [2^13, 2^14): the low
 // halves w_lo = fp16(w' - fp16(w')) of all but vanishing weights are then normal fp16 numbers (unscaled they would sit in the
 // subnormal range and carry ~3e-6 relative error); oscale[n] = 2^-e(n) multiplies the accumulator in the epilogue (exact).
-// K holds three passes over the (chunk-padded) input channels: w_hi, w_hi, w_lo -- against x_hi, x_lo, x_hi.
+// K holds three passes over the (chunk-padded) input channels: w_hi, w_lo, w_hi -- against x_lo, x_hi, x_hi (see x3_chunk).
 size_t packed_weight_bytes_x3(int cout, int cin, int k, int chunk_bytes) {
     const int epb = chunk_bytes / 2;
     return packed_weight_bytes(PREC_F16, cout, 3 * ((cin + epb - 1) / epb * epb), k, chunk_bytes);
@@ -2232,7 +2235,7 @@ void pack_weights_x3(const float* W, int cout, int cin, int k, void* dst, float*
                 const f16 hi = (f16)v, lo = (f16)(v - (float)hi);
                 for (int pass = 0; pass < 3; ++pass) {
                     const int cv = pass * cinp + c;
-                    o[(((size_t)(cv / epb) * taps + t) * cp + row) * epb + (cv % epb)] = pass == 2 ? lo : hi;
+                    o[(((size_t)(cv / epb) * taps + t) * cp + row) * epb + (cv % epb)] = pass == 1 ? lo : hi;
                 }
             }
     }

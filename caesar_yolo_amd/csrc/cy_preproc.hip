@@ -184,7 +184,11 @@ struct TileView {
 struct ClipSet { double L, U; int use_box, bx0, bx1, by0, by1; float Lf, Uf; };
 __device__ __forceinline__ float f_not_below(double x) { float f = (float)x; if ((double)f < x) f = nextafterf(f, INFINITY); return f; }
 __device__ __forceinline__ float f_not_above(double x) { float f = (float)x; if ((double)f > x) f = nextafterf(f, -INFINITY); return f; }
-__device__ __forceinline__ void set_bounds(ClipSet& cs, double L, double U) { cs.L = L; cs.U = U; cs.Lf = f_not_below(L); cs.Uf = f_not_above(U); }
+// (the fp32 bounds are clamped to +-FLT_MAX: the open initial set [-inf, +inf] then still rejects a non-finite raw pixel, as the
+// reference's isfinite mask does -- cy_preproc / cy_detect_tiles accept buffers that did not go through cy_mosaic_prepare)
+__device__ __forceinline__ void set_bounds(ClipSet& cs, double L, double U) {
+    cs.L = L; cs.U = U; cs.Lf = fmaxf(f_not_below(L), -3.402823466e+38f); cs.Uf = fminf(f_not_above(U), 3.402823466e+38f);
+}
 
 // One pass over the tile.  A thread owns groups of FOUR consecutive pixels of a row (one 16-byte buffer load, alignment 4)
 // and keeps PXG groups in flight: every statistics pass re-reads the raw tile (1-1.6 MB per workgroup, far more than an

@@ -49,7 +49,8 @@ struct cy_ctx {
     hipEvent_t ev_call = nullptr, ev_pre[3] = {nullptr, nullptr, nullptr}, ev_fwd[3] = {nullptr, nullptr, nullptr}, ev_post[3] = {nullptr, nullptr, nullptr};
     unsigned long batches = 0;                          // cy_detect_tiles calls on the main pipeline since load / flush
     unsigned long small_batches = 0;                    // ... and on the small-batch lane (buffer set 2, forward on s_fwd2)
-    bool mosaic_dirty = true;                           // cy_mosaic_prepare ran on the caller's stream since the last cy_detect_tiles
+    bool mosaic_dirty = true;                           // cy_mosaic_prepare / cy_detect_fence ran on the caller's stream since the last cy_detect_tiles
+    const void* seen_mosaic[16] = {nullptr}; int n_seen = 0;   // mosaic buffers already ordered behind the caller's stream in this pipeline
     int* counters = nullptr;                            // device: [0] degenerate boxes dropped by the IoU merge, [1] tiles whose candidates overflowed `cap`
     // optional per-launch timing of the forward ops (hipEvents on the caller's stream)
     bool profiling = false;
@@ -180,7 +181,7 @@ bool bneck_pair(const Plan& p, size_t i) {
 // tensor, or the kernels would address outside the workspace (the tensors' extents are the buffer-resource bounds).
 std::string validate_plan(const Plan& p) {
     auto T = [&](int t) -> const Tensor& { return p.tensors[t]; };
-    auto inside = [&](int t, int coff, int n) { return coff >= 0 && n >= 1 && coff + n <= T(t).C; };
+    auto inside = [&](int t, int coff, int n) { return coff >= 0 && n >= 1 && (long)coff + n <= T(t).C; };      // (untrusted u32 fields: no int overflow)
     for (size_t i = 0; i < p.ops.size(); ++i) {
         const Op& o = p.ops[i];
         const std::string at = " in op " + std::to_string(i);
@@ -192,7 +193,7 @@ std::string validate_plan(const Plan& p) {
         if (o.kind == OPK_ATTN) {
             const long need = (long)o.p0 * (2L * o.p1 + o.p2);
             if (o.out < 0 || o.p0 < 1 || o.p1 < 1 || o.p2 < 1 || need > 65536 || !inside(o.in0, o.in0_coff, (int)need) ||
-                !inside(o.out, o.out_coff, o.p0 * o.p2))
+                (long)o.p0 * o.p2 > 65536 || !inside(o.out, o.out_coff, o.p0 * o.p2))
                 return "attention slice outside its tensor" + at;
             continue;
         }
@@ -536,8 +537,7 @@ static int ensure_second_workspace(cy_ctx* c) {
 // leaves free instead of competing with it.
 static int ensure_small_lane(cy_ctx* c) {
     if (c->ws3) return CY_OK;
-    c->ws3_bytes = c->ws_bytes / 4 + (1u << 20);            // 63 of at least 64 x 4 tiles... sized for < 64 tiles of a context built for >= 64
-    if (c->cfg.max_batch < 256) c->ws3_bytes = c->ws_bytes;
+    c->ws3_bytes = c->ws_bytes / 3 + (1u << 20);            // a small batch holds at most max_batch / 3 tiles
     HIPCHK(c, hipMalloc(&c->ws3, c->ws3_bytes));
     int prio_lo = 0, prio_hi = 0;
     hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
@@ -549,7 +549,7 @@ static int dual_mode() { const char* e = getenv("CY_DUAL_FORWARD"); return e ? a
 
 static int forward_split(cy_ctx* c, const void* d_netin, int B, int H, int W, float* d_pred, hipStream_t sm) {
     const int mode = dual_mode();
-    const bool split = c->prec == PREC_F16 && mode != 0 && B >= 2 && (mode > 1 || (B >= 64 && B < 240));
+    const bool split = c->prec == PREC_F16 && mode != 0 && B >= 2 && (mode > 1 || (B >= 64 && B < 240));      // (fp16x3: a 128-tile batch already fills the chip 3x longer per launch)
     c->split_last = split;
     if (!split) return forward_on(c, d_netin, B, H, W, d_pred, sm, c->ws, c->ws_bytes, true);
     int rc0 = ensure_second_workspace(c);
@@ -985,6 +985,9 @@ static int fill_pre_args(cy_ctx* c, const float* d_mosaic, int MH, int MW, const
         if (h_tiles[2 * b] < 0 || h_tiles[2 * b + 1] < 0 || h_tiles[2 * b] + tw > MW || h_tiles[2 * b + 1] + th > MH)
             return fail(c, CY_ERR_ARG, "tile outside the mosaic");
     }
+    // the statistics passes address a tile through a raw buffer resource with 32-bit byte offsets
+    if (((long)(th - 1) * MW + tw) * 4L > 0xFFFFFF00L)
+        return fail(c, CY_ERR_UNSUPPORTED, "tile rows span more than 4 GiB of the mosaic: crop the image or run it in tiles");
     a.mosaic = d_mosaic; a.MH = MH; a.MW = MW; a.B = B; a.th = th; a.tw = tw;
     a.nprog = cfg->nprog;
     for (int i = 0; i < 3; ++i) {
@@ -1109,8 +1112,10 @@ int cy_detect_tiles(cy_ctx* c, const float* d_mosaic, int MH, int MW, const int*
     // workgroups each -- 4.2 ms for ONE tile, 6.2 ms for 39, i.e. 8 % of a pass for 4 % of its pixels when run in line -- but
     // hardly any work: beside the full batches of the main lane it costs about its share of the chip.  The caller
     // interleaves them with the full batches (TileEngine).  CY_SMALL_LANE=0 keeps every batch on the main lane.
-    static const int small_lane = env_knob("CY_SMALL_LANE", 1);
-    const bool small = small_lane && c->prec == PREC_F16 && B < 64 && c->cfg.max_batch >= 64;    // (contexts sized for tile batches only)
+    // "small" is relative to the context: at most a third of max_batch (and < 64 tiles).  With the CLI default --tile_batch 64
+    // the equal-sized batches of 50-63 tiles stay on the main lane with its two buffer sets (the lane has ONE set: consecutive
+    // small batches serialise preprocessing behind forward).  CY_SMALL_LANE is read per call (the tests compare both settings).
+    const bool small = env_knob("CY_SMALL_LANE", 1) && c->prec != PREC_F32 && B < 64 && (long)B * 3 <= c->cfg.max_batch;
     int rc = CY_OK;
     if (small) { rc = ensure_small_lane(c); if (rc) return rc; }
     const int sl = small ? 2 : (int)(c->batches & 1);
@@ -1120,9 +1125,14 @@ int cy_detect_tiles(cy_ctx* c, const float* d_mosaic, int MH, int MW, const int*
     // order the side streams after whatever the caller already queued on `stream` -- only where that matters: the first batch
     // after load / flush, or after cy_mosaic_prepare.  Later batches are ordered by ev_fwd / ev_post alone, so that the
     // preprocessing of batch i does not wait for the forward of batch i-1 that is already queued on `stream`.
-    if (c->batches + c->small_batches == 0 || c->mosaic_dirty) {
+    // A mosaic buffer this pipeline has not seen yet may still be the target of an upload queued on `stream`: order behind it too.
+    bool seen = false;
+    for (int i = 0; i < c->n_seen; ++i) seen = seen || c->seen_mosaic[i] == (const void*)d_mosaic;
+    if (c->batches + c->small_batches == 0 || c->mosaic_dirty || !seen) {
         HIPCHK(c, hipEventRecord(c->ev_call, sm));
         HIPCHK(c, hipStreamWaitEvent(c->s_pre, c->ev_call, 0));
+        if (c->mosaic_dirty || c->batches + c->small_batches == 0) c->n_seen = 0;
+        if (c->n_seen < 16) c->seen_mosaic[c->n_seen++] = d_mosaic;        // (a 17th distinct buffer is simply ordered again every time)
         c->mosaic_dirty = false;
     }
     if (reuse) HIPCHK(c, hipStreamWaitEvent(c->s_pre, c->ev_fwd[sl], 0));
@@ -1149,6 +1159,13 @@ int cy_detect_tiles(cy_ctx* c, const float* d_mosaic, int MH, int MW, const int*
     return CY_OK;
 }
 
+int cy_detect_fence(cy_ctx* c, void* stream) {
+    if (!c || !c->loaded) return fail(c, CY_ERR_STATE, "weights not loaded");
+    (void)stream;
+    c->mosaic_dirty = true;                  // the next cy_detect_tiles records an event on ITS stream and orders the side streams behind it
+    return CY_OK;
+}
+
 int cy_detect_flush(cy_ctx* c, void* stream) {
     if (!c || !c->loaded) return fail(c, CY_ERR_STATE, "weights not loaded");
     hipStream_t sm = (hipStream_t)stream;
@@ -1162,7 +1179,7 @@ int cy_detect_flush(cy_ctx* c, void* stream) {
         HIPCHK(c, hipStreamWaitEvent(sm, c->ev_post[2], 0));
         HIPCHK(c, hipStreamWaitEvent(sm, c->ev_pre[2], 0));
     }
-    c->batches = 0; c->small_batches = 0;     // the next call starts a new pipeline: it orders the side streams behind `stream` again
+    c->batches = 0; c->small_batches = 0; c->n_seen = 0;     // the next call starts a new pipeline: it orders the side streams behind `stream` again
     return CY_OK;
 }
 

@@ -186,8 +186,9 @@ class TileEngine(object):
         # Launch order: the small batches (ragged edge classes, < 64 tiles) are slotted between the full ones -- the library runs
         # their forward on a second stream (cy_detect_tiles, "small-batch lane"), where a chain of ~105 tiny kernels costs its
         # share of the chip instead of its latency (4-6 ms each in line on the 16k mosaic).  Output rows stay where they were.
-        big = [p for p in self.plan if p[2] >= 64]
-        small = [p for p in self.plan if p[2] < 64]
+        is_small = lambda p: p[2] < 64 and p[2] * 3 <= detector.max_batch       # the library's rule (cy_detect_tiles)
+        big = [p for p in self.plan if not is_small(p)]
+        small = [p for p in self.plan if is_small(p)]
         if big and small:
             order = []
             for i, p in enumerate(big):

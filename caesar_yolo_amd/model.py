@@ -249,6 +249,11 @@ class HipDetector(object):
         """Order the current stream behind every batch queued by detect_tiles (they run on internal side streams)."""
         self._chk(self.lib.cy_detect_flush(self.ctx, self._stream()))
 
+    def fence(self):
+        """Work queued on the current stream since the last detect_tiles call (an upload into a mosaic buffer already in use, a
+        memset of an output buffer) is ordered before the next call's internal streams (cy_detect_fence)."""
+        self._chk(self.lib.cy_detect_fence(self.ctx, self._stream()))
+
     def counters(self, reset=False):
         """-> dict(degenerate_boxes, cand_overflow_tiles) accumulated since the last reset (synchronises the device)."""
         out = (C.c_longlong * 4)()

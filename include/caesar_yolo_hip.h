@@ -144,6 +144,14 @@ int cy_detect_tiles(cy_ctx* ctx, const float* d_mosaic, int MH, int MW, const in
                     float* d_out, int* d_out_count, int* d_status, void* stream);
 
 int cy_detect_flush(cy_ctx* ctx, void* stream);
+/* Ordering contract of unflushed cy_detect_tiles calls.  The internal streams are ordered behind `stream` (everything the caller
+ * queued on it so far) at: the first call after cy_load_weights / cy_detect_flush; the first call after cy_mosaic_prepare; the
+ * first call that names a d_mosaic buffer this pipeline has not seen yet; the first call after cy_detect_fence.  Any OTHER work
+ * the caller queues on `stream` between two unflushed calls -- a re-upload into a mosaic buffer already used, a memset of an
+ * output buffer -- is NOT ordered before the internal streams touch those buffers: call cy_detect_fence after queuing it (the
+ * next cy_detect_tiles then waits for it; costs the overlap of that one batch's preprocessing with the previous forward), or
+ * prepare every buffer before the first call (what caesar_yolo_amd.inference.TileEngine does). */
+int cy_detect_fence(cy_ctx* ctx, void* stream);
 
 /* events the reference would not survive silently, accumulated over cy_decode_nms / cy_iou_merge / cy_detect_tiles calls:
  * out4[0] degenerate boxes (x1 >= x2 or y1 >= y2) dropped before the IoU merge -- the reference aborts on them inside

@@ -34,6 +34,98 @@ FP16_MIN_MATCHED = 0.95          # after the IoU merge and in the final catalog:
 FP16_MAX_EXTRA = 0.05
 
 
+# bounds of the parity contexts over ALL kept anchors of a config (641 / 1183 / 7500 boxes; the single-image tests assert 5e-3 px):
+# the north star's own bar, 1e-4 in normalised image coordinates (0.051 px at 512, 0.064 px at 640), and 2e-5 on scores.
+# Measured max |dbox| (PARITYSET lines): fp32 7.1e-3 / 7.3e-3 / 3.5e-2 px, fp16x3 2.0e-3 / 9.5e-3 / 1.6e-2 px
+# on C2 / C3 / C5 (the tail of 7500 broad random-init DFL distributions); scores <= 1.3e-5 / 5.8e-6.
+PARITY_BOX_NORM, PARITY_SCORE = 1e-4, 2e-5
+
+
+def _stagewise(name, prec):
+    """One BASELINE config at reduced size through the stage entry points (preproc -> forward -> decode/NMS -> IoU merge), per
+    shape class.  -> per tile {tid: dict(kept=(boxes, scores, classes, anchors), merged=(boxes, scores, classes))}, letterbox."""
+    from caesar_yolo_amd.model import YOLO
+    ref = CC.oracle_run(name)
+    img, ts, step, imgsz, spec = CC.config_input(name)
+    model = YOLO(seeded_weights()[0], precision=prec, max_batch=32, max_imgsz=imgsz, device=0)
+    eng = model.engine()
+    mosaic = eng.mosaic_to_device(img)
+    cfg = CC.device_pipeline(spec).program()
+    classes = {}
+    for tid, t in enumerate(ref["grid"]):
+        classes.setdefault((t[3] - t[2], t[1] - t[0]), []).append(tid)
+    out = {}
+    for (th, tw), tids in classes.items():
+        xy = [(ref["grid"][t][0], ref["grid"][t][2]) for t in tids]
+        netin, status, lb = eng.preproc(mosaic, xy, th, tw, imgsz, cfg)
+        pred = eng.forward(netin)
+        d, anch, cnt = eng.decode_nms(pred, lb.H, lb.W, th, tw, CC.CONF, CC.IOU)
+        m, mcnt, _ = eng.iou_merge(d, cnt, CC.CONF, CC.SOFT, CC.HARD)
+        torch.cuda.synchronize()
+        status, d, anch, cnt, m, mcnt = (x.cpu().numpy() for x in (status, d, anch, cnt, m, mcnt))
+        for b, t in enumerate(tids):
+            assert (status[b] != 0) == (t in ref["skipped"]), "tile %d rejection differs" % t
+            if status[b] != 0:
+                continue
+            n, k = int(cnt[b]), int(mcnt[b])
+            out[t] = dict(kept=(d[b, :n, :4], d[b, :n, 4], d[b, :n, 5], anch[b, :n]), merged=(m[b, :k, :4], m[b, :k, 4], m[b, :k, 5]),
+                          HW=(lb.H, lb.W))
+    eng.close()
+    return out
+
+
+def _kept_set_report(name, prec):
+    """The north star's "kept-box index set after NMS" for a parity context.  Per tile: the anchors the two runs disagree on, and
+    whether each of them is a TIE at a cut -- its score within PARITY_SCORE of the conf threshold, or of the score of the last
+    box kept when max_det = 300 truncates the list (two anchors whose scores differ by one fp32 ulp swap places there under any
+    re-ordering of an fp32 sum, also between two runs of the reference on different CPUs).  Ties are counted and printed; any
+    other disagreement fails.  Common anchors: box / score deltas recorded (asserted by the caller), classes equal; the ORDER
+    of the kept list must agree up to permutations inside groups of scores closer than PARITY_SCORE."""
+    ref = CC.oracle_run(name)
+    got = _stagewise(name, prec)
+    rep = dict(tiles=0, kept_ref=0, kept_got=0, common=0, ties=0, order_swaps=0, max_dbox=0.0, max_dscore=0.0, tie_tiles=[])
+    for t, g in got.items():
+        rb, rs, rc, ra = ref["raw"][t]
+        gb, gs, gc, ga = g["kept"]
+        rep["tiles"] += 1; rep["kept_ref"] += len(ra); rep["kept_got"] += len(ga)
+        gi = {int(a): i for i, a in enumerate(ga)}
+        ri = {int(a): i for i, a in enumerate(ra)}
+        last = min(float(gs[-1]) if len(gs) == 300 else 2.0, float(rs[-1]) if len(rs) == 300 else 2.0)     # the max_det cut, if it binds
+        for a in set(gi) ^ set(ri):
+            sc = float(gs[gi[a]]) if a in gi else float(rs[ri[a]])
+            tie = abs(sc - CC.CONF) <= PARITY_SCORE or abs(sc - last) <= PARITY_SCORE
+            assert tie, "%s %s tile %d: anchor %d (score %.7f) is kept by one run only and is no tie (conf %.1f, last kept %.7f)" % (
+                name, prec, t, a, sc, CC.CONF, last)
+            rep["ties"] += 1
+            if t not in rep["tie_tiles"]:
+                rep["tie_tiles"].append(t)
+        for a, i in gi.items():
+            j = ri.get(a)
+            if j is None:
+                continue
+            rep["common"] += 1
+            assert int(gc[i]) == int(rc[j]), (name, prec, t, a)
+            rep["max_dbox"] = max(rep["max_dbox"], float(np.abs(gb[i] - rb[j]).max()))
+            rep["max_dscore"] = max(rep["max_dscore"], float(abs(gs[i] - rs[j])))
+            if i != j:
+                rep["order_swaps"] += 1
+                assert abs(float(rs[j]) - float(rs[min(i, len(rs) - 1)])) <= PARITY_SCORE, "%s %s tile %d: anchor %d at rank %d vs %d is no score tie" % (name, prec, t, a, i, j)
+    return rep, got, ref
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16x3"])
+@pytest.mark.parametrize("name", ["C2", "C3", "C5"])
+def test_config_parity_context_kept_anchor_sets(name, prec):
+    """Parity bar of the north star on the reduced BASELINE configs, for both parity contexts: kept-anchor set after NMS identical
+    to the oracle's (ties at a cut counted, see _kept_set_report), boxes within 1e-4 of the image size and scores within 2e-5 on every kept anchor."""
+    rep, _, _ = _kept_set_report(name, prec)
+    print("PARITYSET %s" % json.dumps(dict(config=name, precision=prec, **rep)))
+    assert rep["kept_ref"] > 100 and rep["common"] >= rep["kept_ref"] - rep["ties"]
+    imgsz = CC.config_input(name)[3]
+    assert rep["max_dbox"] <= PARITY_BOX_NORM * imgsz and rep["max_dscore"] <= PARITY_SCORE, rep
+    assert rep["ties"] <= 4, rep
+
+
 def _run_sfinder(tmp_path, name, precision, batch=32):
     from caesar_yolo_amd.inference import SFinder
     from caesar_yolo_amd.model import YOLO
@@ -87,7 +179,18 @@ def test_config_catalog_fp32_matches_oracle(name, prec, tmp_path):
     assert sum(1 for s in ref["catalog"] if s["merged"]) >= min_merged
     got, stats = _run_sfinder(tmp_path, name, prec)
     assert stats["tiles"] == ntiles and stats["skipped"] == nrej
-    assert stats["per_tile_detections"] == sum(len(d[1]) for d in ref["dets"] if d is not None)
+    nref = sum(len(d[1]) for d in ref["dets"] if d is not None)
+    if stats["per_tile_detections"] != nref or len(got) != len(ref["catalog"]):
+        # the only admissible cause: score ties at a cut (conf threshold / max_det truncation), see _kept_set_report -- which asserts
+        # that every disagreement of the kept sets IS such a tie.  A tie moves at most one detection per tied anchor.
+        rep, _, _ = _kept_set_report(name, prec)
+        assert rep["ties"] > 0, "catalog differs from the oracle's although the kept-anchor sets agree"
+        cat = CC.match_sets(CC.sources_as_sets(got), CC.sources_as_sets(ref["catalog"]))
+        print("%s %s: %d score ties at a cut (tiles %s) -> per-tile detections %d vs %d, catalog %s" % (
+            name, prec, rep["ties"], rep["tie_tiles"], stats["per_tile_detections"], nref, cat))
+        assert abs(stats["per_tile_detections"] - nref) <= rep["ties"]
+        assert cat["missing"] + cat["extra"] <= 2 * rep["ties"] and cat["max_dscore"] <= PARITY_SCORE
+        return
     off = _compare_exact(got, ref["catalog"])
     print("%s %s: %d sources (%d merged across tiles), %d of %d integer coordinates differ by one" % (
         name, prec, len(got), sum(1 for s in got if s["merged"]), off, 4 * len(got)))
@@ -98,35 +201,12 @@ def test_config_catalog_fp32_matches_oracle(name, prec, tmp_path):
 def test_config_fp16_delta_vs_oracle(name, tmp_path):
     """The benchmarked mode against the oracle on the same tiles, at three levels: kept anchors after NMS, per-tile
     detections after the IoU merge, final catalog.  Prints one FP16DELTA line (tools/fp16_delta.py collects them)."""
-    from caesar_yolo_amd.model import YOLO
     ref = CC.oracle_run(name)
-    img, ts, step, imgsz, spec = CC.config_input(name)
-    model = YOLO(seeded_weights()[0], precision="fp16", max_batch=32, max_imgsz=imgsz, device=0)
-    eng = model.engine()
-    mosaic = eng.mosaic_to_device(img)
-    cfg = CC.device_pipeline(spec).program()
-    classes = {}
-    for tid, t in enumerate(ref["grid"]):
-        classes.setdefault((t[3] - t[2], t[1] - t[0]), []).append(tid)
     nms_reports, reports, nref = [], [], 0
-    for (th, tw), tids in classes.items():
-        xy = [(ref["grid"][t][0], ref["grid"][t][2]) for t in tids]
-        netin, status, lb = eng.preproc(mosaic, xy, th, tw, imgsz, cfg)
-        pred = eng.forward(netin)
-        d, anch, cnt = eng.decode_nms(pred, lb.H, lb.W, th, tw, CC.CONF, CC.IOU)
-        m, mcnt, _ = eng.iou_merge(d, cnt, CC.CONF, CC.SOFT, CC.HARD)
-        torch.cuda.synchronize()
-        status, d, anch, cnt, m, mcnt = (x.cpu().numpy() for x in (status, d, anch, cnt, m, mcnt))
-        for b, t in enumerate(tids):
-            assert (status[b] != 0) == (t in ref["skipped"]), "tile %d rejection differs" % t
-            if status[b] != 0:
-                continue
-            n = int(cnt[b])
-            nms_reports.append(CC.nms_level_report((d[b, :n, :4], d[b, :n, 4], d[b, :n, 5], anch[b, :n]), ref["raw"][t], lb.H, lb.W))
-            k = int(mcnt[b])
-            reports.append(CC.match_sets((m[b, :k, :4], m[b, :k, 4], m[b, :k, 5]), ref["dets"][t]))
-            nref += len(ref["dets"][t][1])
-    eng.close()
+    for t, g in _stagewise(name, "fp16").items():
+        nms_reports.append(CC.nms_level_report(g["kept"], ref["raw"][t], *g["HW"]))
+        reports.append(CC.match_sets(g["merged"], ref["dets"][t]))
+        nref += len(ref["dets"][t][1])
     nms_rep, tile_rep = CC.sum_nms_reports(nms_reports), CC.sum_reports(reports)
     cat16, _ = _run_sfinder(tmp_path, name, "fp16")
     cat_rep = CC.match_sets(CC.sources_as_sets(cat16), CC.sources_as_sets(ref["catalog"]))

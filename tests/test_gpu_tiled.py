@@ -209,3 +209,48 @@ def test_batch_invariant_detections_do_not_depend_on_batching(monkeypatch):
         if a is not None:
             np.testing.assert_array_equal(a, b)
             np.testing.assert_array_equal(a, c)
+
+
+def test_small_batch_lane_and_fence(monkeypatch):
+    """cy_detect_tiles' small-batch lane (batches of at most a third of max_batch on their own stream / buffer set / workspace) gives
+    the same bits as the main lane (CY_SMALL_LANE is read per call), and the ordering contract of unflushed calls holds: a memset
+    of an output buffer queued on the caller's stream BETWEEN two unflushed calls is ordered before the next call's internal
+    streams by cy_detect_fence (include/caesar_yolo_hip.h), so the results land after it."""
+    from caesar_yolo_amd.model import YOLO
+    from caesar_yolo_amd import preprocessing as PP
+    monkeypatch.delenv("CY_BATCH_INVARIANT", raising=False)
+    img = np.load(os.path.join(ROOT, "tests/golden/mosaic_c.npz"))["img"].astype(np.float32)
+    model = YOLO(seeded_weights()[0], precision="fp16", max_batch=12, max_imgsz=256, device=0)
+    det = model.engine()
+    mosaic = det.mosaic_to_device(img)
+    cfg = PP.DataPreprocessor([PP.ZScaleTransformer([0.25] * 3), PP.MinMaxNormalizer(0, 255)]).program()
+    big = [(64 * i, 40 * (i % 3)) for i in range(9)]            # 9 tiles: main lane (9 * 3 > 12)
+    small = [(600, 400), (300, 200), (128, 128)]                 # 3 tiles: small lane (3 * 3 <= 12)
+    args = (256, 256, 256, cfg, 0.3, IOU, SOFT, HARD)
+
+    def run(lane, fenced):
+        monkeypatch.setenv("CY_SMALL_LANE", lane)
+        seq = (big, small, big, small)
+        # every output buffer exists and is filled BEFORE the first call (the contract for work that is not fenced)
+        outs = [(torch.full((len(xy), 300, 6), 7.0, device="cuda"), torch.full((len(xy),), 77, dtype=torch.int32, device="cuda"),
+                 torch.full((len(xy),), 7, dtype=torch.int32, device="cuda")) for xy in seq]
+        torch.cuda.synchronize()
+        for k, (xy, o) in enumerate(zip(seq, outs)):
+            if fenced and k > 0:
+                for t in o:
+                    t.zero_()                                    # queued on the caller's stream between unflushed calls
+                det.fence()
+            det.detect_tiles(mosaic, xy, *args, out=o, flush=False)
+        det.flush()
+        torch.cuda.synchronize()
+        return [(d.cpu().numpy(), c.cpu().numpy(), s.cpu().numpy()) for d, c, s in outs]
+    ref = run("0", False)
+    assert sum(int(c.sum()) for _, c, _ in ref) >= 8 and all((c < 77).all() and (s == 0).all() for _, c, s in ref)
+    for lane, fenced in (("1", False), ("1", True), ("0", True)):
+        got = run(lane, fenced)
+        for (d0, c0, s0), (d1, c1, s1) in zip(ref, got):
+            np.testing.assert_array_equal(c0, c1)
+            np.testing.assert_array_equal(s0, s1)
+            for b in range(len(c0)):
+                np.testing.assert_array_equal(d0[b, :c0[b]], d1[b, :c0[b]])
+    det.close()
