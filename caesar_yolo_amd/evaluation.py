@@ -53,8 +53,10 @@ class Analyzer(object):
             logger.error("No input image given!")
             return -1
         image = np.asarray(image)
+        if image.ndim == 3 and image.shape[2] == 3:
+            return self._predict_cube(image, image_id, xmin, ymin)      # caller-supplied 3-channel image (evaluation.py:146-154: taken as is)
         if image.ndim != 2:
-            logger.error("The HIP path takes single-channel 2-D frames (the 3-channel cube is built on device)")
+            logger.error("Expected a 2-D frame or an (H,W,3) image, got shape %s" % (image.shape,))
             return -1
         if image_id:
             self.image_id = image_id
@@ -72,7 +74,56 @@ class Analyzer(object):
         except L.CyError as e:
             logger.warning("Model prediction failed (err=%s)..." % str(e))
             return -1
-        st = int(status[0])
+        return self._finish(det, d, cnt, int(status[0]), nx, ny, xmin, ymin,
+                            lambda: det.preproc_planes(mosaic, [(0, 0)], ny, nx, cfg)[0][0])
+
+    def _predict_cube(self, image, image_id, xmin, ymin):
+        """An (H,W,3) array whose channels differ (the reference takes it as is, caesar_yolo/evaluation.py:146-154, and every CLI
+        stage maps channel c of its input to channel c of its output): each plane goes through ITS channel's program on the device
+        (cy_preproc_planes), the three float64 results are the cube handed to the model's own LetterBox (cy_letterbox_pack) ->
+        forward -> decode/NMS -> IoU merge.  Pixel values are taken as fp32, like FITS pixels; the constant-row check
+        (:171-176, rows 0..2 of the cube, Q1) runs on the host over the three rows it reads."""
+        import copy
+        if image_id:
+            self.image_id = image_id
+        self.image_xmin, self.image_ymin = xmin, ymin
+        dev = None if str(self.device) == "" else self.device
+        ny, nx = image.shape[:2]
+        try:
+            det = self.model.engine(dev)
+            dp = self.config.get('preprocess_fcn')
+            cfg = dp.program() if dp is not None else no_preprocessing()
+            planes, st = [], 0
+            for c in range(3):
+                cfg_c = copy.copy(cfg)
+                if cfg.nprog == 3:                                 # this channel's program alone, replicated
+                    cfg_c = type(cfg)()
+                    cfg_c.nprog = 1
+                    cfg_c.prog[0] = cfg.prog[c]
+                mosaic = det.mosaic_to_device(np.ascontiguousarray(image[:, :, c], dtype=np.float32))
+                pl, status = det.preproc_planes(mosaic, [(0, 0)], ny, nx, cfg_c)
+                torch.cuda.synchronize(det.tdev)
+                if int(status[0]) == 1:
+                    st = 1
+                planes.append(pl[0, 0])
+            cube = torch.stack(planes, 0)[None].contiguous()        # [1,3,H,W] float64 on device (a copy, no arithmetic)
+            if st == 0:
+                rows = cube[0, :, :3, :].cpu().numpy()              # rows 0..2 of the (H,W,3) image = [3 ch, 3 rows, W]
+                if any(rows[:, i, :].min() == rows[:, i, :].max() for i in range(min(3, ny))):
+                    st = 2
+            d = cnt = None
+            if st == 0:
+                netin, lb = det.letterbox_pack(cube, self.imgsize)
+                pred = det.forward(netin)
+                dn, _, cn = det.decode_nms(pred, lb.H, lb.W, ny, nx, self.score_thr, self.iou_thr)
+                d, cnt, _ = det.iou_merge(dn, cn, self.score_thr, self.merge_overlap_iou_thr_soft, self.merge_overlap_iou_thr_hard)
+                torch.cuda.synchronize(det.tdev)
+        except L.CyError as e:
+            logger.warning("Model prediction failed (err=%s)..." % str(e))
+            return -1
+        return self._finish(det, d, cnt, st, nx, ny, xmin, ymin, lambda: cube[0])
+
+    def _finish(self, det, d, cnt, st, nx, ny, xmin, ymin, planes_fn):
         if st == 1:
             logger.warning("Input image is None, no prediction made.")
             return -1
@@ -80,8 +131,7 @@ class Analyzer(object):
             logger.warning("Input image pixels have the same value in one of the first rows, no prediction made.")
             return -1
         if self.draw or self.save_img:
-            planes, _ = det.preproc_planes(mosaic, [(0, 0)], ny, nx, cfg)
-            self.image = np.ascontiguousarray(planes[0].cpu().numpy().transpose(1, 2, 0))
+            self.image = np.ascontiguousarray(planes_fn().cpu().numpy().transpose(1, 2, 0))
         dd = d[0, :int(cnt[0])].cpu().numpy()
         self.bboxes_final = [dd[i, :4].copy() for i in range(dd.shape[0])]
         self.scores_final = [dd[i, 4] for i in range(dd.shape[0])]

@@ -457,6 +457,23 @@ class SFinder(object):
             logger.error("Failed to read image %s!" % path)
             return -1
         data, self.header = res
+        # sub-image of the serial run (caesar_yolo/inference.py:499-505 -> utils.read_fits_crop, utils.py:340-394): ranges all 0 / -1 =
+        # the whole image; otherwise [ymin:ymax, xmin:xmax] with the max pixel EXCLUDED, the same argument errors, and catalog
+        # coordinates relative to the crop (the reference hands the crop to Analyzer.predict without an origin)
+        c = self.config
+        rng = [int(c.get(k, 0)) for k in ('image_xmin', 'image_xmax', 'image_ymin', 'image_ymax')]
+        if not all(v in (0, -1) for v in rng):
+            ixmin, ixmax, iymin, iymax = rng
+            if ixmin < 0 or ixmax < 0 or iymin < 0 or iymax < 0:
+                logger.error("ixmin/ixmax/iymin/iymax must be >0")
+                return -1
+            if ixmax <= ixmin or iymax <= iymin:
+                logger.error("ixmax must be >ixmin and iymax >iymin!")
+                return -1
+            data = data[iymin:iymax, ixmin:ixmax]                  # a view of the memory map: only the crop is uploaded
+            if data.size == 0:
+                logger.error("Failed to read data in range[%d:%d,%d:%d] from file %s!" % (iymin, iymax, ixmin, ixmax, path))
+                return -1
         self.image_id = utils.image_id_of(path)
         self.ny, self.nx = data.shape
         self._beam_info()

@@ -9,7 +9,8 @@ Differences that come with the MI355X engine:
   --max_ntasks_per_worker  has no default here (the reference's 100 would refuse BASELINE configs 3-5); given, it is honoured;
   multi-GPU  = one process per GPU: `python -m torch.distributed.run --nproc-per-node N scripts/run.py ...`
              (replaces `mpirun -np N`, test/run_inference_parallel.sh:47-52);
-  --precision fp32|fp16 (default fp32 = parity mode; fp16 = throughput mode), --tile_batch N  are new.
+  --precision fp16x3|fp32|fp16 (default fp16x3 = the fast parity context: fp16 high + low halves, fp32 accumulate; fp32 = exact fp32
+  FMA chains, 2.7x slower; fp16 = throughput mode, 3x faster, ~2 % of detections differ), --tile_batch N  are new.
 """
 import argparse
 import logging
@@ -74,7 +75,7 @@ def parse_args(argv=None):
         p.add_argument('--' + a, dest=a, action='store_true')
     p.add_argument('--detect_outfile', type=str, default="")
     p.add_argument('--detect_outfile_json', type=str, default="")
-    p.add_argument('--precision', type=str, default="fp32", choices=["fp16", "fp32"],
+    p.add_argument('--precision', type=str, default="fp16x3", choices=["fp16", "fp16x3", "fp32"],
                    help='fp32 (default): exact-fp32 kernels, detections match the reference CPU run to 1e-4; fp16: fp16 operands / '
                         'fp32 accumulate, ~16x the throughput, 2-3 %% of the detections differ (DESIGN.md section 2)')
     p.add_argument('--tile_batch', type=int, default=64)
@@ -94,8 +95,10 @@ def validate_args(args):
     if not args.weights.startswith("seeded:") and not os.path.isfile(args.weights):
         logger.error("Given weight file %s not existing or not a file!" % args.weights)
         return -1
-    if args.xmin >= 0 or args.xmax >= 0 or args.ymin >= 0 or args.ymax >= 0:
-        logger.error("Sub-image ranges are not supported (they are broken in the reference too: inference.py:374-381)")
+    if args.split_img_in_tiles and (args.xmin >= 0 or args.xmax >= 0 or args.ymin >= 0 or args.ymax >= 0):
+        # serial runs crop like the reference (inference.py:499-505); the tiled run of the reference derives its grid from
+        # attributes it has not set yet when a range is given (inference.py:374-381): refused here
+        logger.error("Sub-image ranges together with --split_img_in_tiles are not supported (broken in the reference: inference.py:374-381)")
         return -1
     return 0
 

@@ -133,3 +133,82 @@ def test_analyzer_plot_and_preprocessed_fits(tmp_path, monkeypatch):
     np.testing.assert_allclose(np.asarray(raw), cube[:, :, 0], rtol=1e-10, atol=1e-12)
     reg = open(tmp_path / "out_galaxy0001.reg").read().splitlines()
     assert reg[1] == "image" and len(reg) == 2 + len(an.bboxes_final)
+
+
+def test_analyzer_predict_three_channel_array():
+    """Analyzer.predict on a caller-supplied (H,W,3) array whose channels DIFFER (caesar_yolo/evaluation.py:146-154 takes a 3-D image as
+    is): each plane through its channel's program on the device, the cube through the model call -- against the oracle pipeline on
+    the same cube.  Also: a cube whose first rows are constant is rejected by the row check (:171-176)."""
+    from caesar_yolo_amd.model import YOLO
+    from caesar_yolo_amd.evaluation import Analyzer
+    from caesar_yolo_amd.config import CONFIG
+    from caesar_yolo_amd import preprocessing as PP
+    from oracle import preprocessing_ref as P
+    from oracle import postproc_ref as R
+    g = np.load(os.path.join(ROOT, "tests/golden/preproc.npz"))
+    base = np.asarray(g["in/big512"][:256, :256], np.float32)
+    cube_in = np.stack([base, base[::-1, :] * 1.5 + 0.001, np.roll(base, 17, axis=1)], axis=2).astype(np.float32)
+    for prec in ("fp32", "fp16x3"):
+        model = YOLO(seeded_weights()[0], precision=prec, max_batch=1, max_imgsz=256)
+        for spec, dpre in (([("zscale", dict(contrasts=[0.25, 0.3, 0.4])), ("minmax", dict(norm_min=0, norm_max=255))],
+                            PP.DataPreprocessor([PP.ZScaleTransformer([0.25, 0.3, 0.4]), PP.MinMaxNormalizer(0, 255)])),):
+            c = dict(CONFIG)
+            c.update(img_size=256, preprocess_fcn=dpre, score_thr=0.05, iou_thr=IOU, merge_overlap_iou_thr_soft=SOFT,
+                     merge_overlap_iou_thr_hard=HARD, devices=["0"])
+            an = Analyzer(model, c)
+            assert an.predict(cube_in, image_id="cube") == 0
+            ref_img = P.build_pipeline(spec)(cube_in.astype(np.float64))
+            det, _, _, _ = oracle_model().predict_raw(ref_img, 256, 0.05, IOU)        # (a cube of unrelated channels scores low on the seeded weights)
+            kb, ks, kc, _ = R.process_detections(det[:, :4].numpy(), det[:, 4].numpy(), det[:, 5].numpy(), 0.05, SOFT, HARD)
+            assert len(an.scores_final) == len(ks) and len(ks) >= 3
+            np.testing.assert_allclose(np.array(an.scores_final), ks, atol=2e-5)
+            np.testing.assert_array_equal(np.array(an.class_ids_final), np.asarray(kc).astype(int))
+            np.testing.assert_allclose(np.array(an.bboxes_final), kb, atol=5e-3)
+        flat = cube_in.copy()
+        flat[:2] = 0.0                                            # rows 0 and 1 all zero in every channel -> constant rows
+        assert Analyzer(model, c).predict(flat, image_id="flat") == -1
+        assert Analyzer(model, c).predict(np.zeros((64, 64, 3), np.float32), image_id="zero") == -1       # pipeline returns None
+        model.engine().close()
+
+
+def test_serial_run_with_sub_image_ranges(tmp_path, monkeypatch):
+    """SFinder.run with --xmin/--xmax/--ymin/--ymax (caesar_yolo/inference.py:499-505 -> utils.read_fits_crop, utils.py:340-394): the crop
+    [ymin:ymax, xmin:xmax] (max excluded) is what the model sees, catalog coordinates are relative to it; the reference's argument
+    errors return -1."""
+    from caesar_yolo_amd.inference import SFinder
+    from caesar_yolo_amd.model import YOLO
+    from caesar_yolo_amd.config import CONFIG
+    from caesar_yolo_amd import preprocessing as PP, utils
+    from oracle import preprocessing_ref as P
+    from oracle import postproc_ref as R
+    monkeypatch.chdir(tmp_path)
+    g = np.load(os.path.join(ROOT, "tests/golden/preproc.npz"))
+    img = np.asarray(g["in/big512"], np.float32)
+    path = str(tmp_path / "big.fits")
+    utils.write_fits_image(path, img)
+    model = YOLO(seeded_weights()[0], precision="fp16x3", max_batch=1, max_imgsz=256)
+
+    def cfg(**kw):
+        c = dict(CONFIG)
+        c.update(image_path=path, img_size=256, score_thr=0.3, iou_thr=IOU, merge_overlap_iou_thr_soft=SOFT, merge_overlap_iou_thr_hard=HARD,
+                 preprocess_fcn=PP.DataPreprocessor([PP.ZScaleTransformer([0.25] * 3), PP.MinMaxNormalizer(0, 255)]), devices=["0"],
+                 save_catalog=True, save_region=False)
+        c.update(kw)
+        return c
+    sf = SFinder(model, cfg(image_xmin=100, image_xmax=340, image_ymin=37, image_ymax=293))
+    assert sf.run() == 0
+    got = json.load(open(tmp_path / "out_big.json"))["objs"]
+    crop = img[37:293, 100:340]
+    dp = P.build_pipeline([("zscale", dict(contrasts=[0.25] * 3)), ("minmax", dict(norm_min=0, norm_max=255))])
+    det, _, _, _ = oracle_model().predict_raw(dp(P.to_cube(crop)), 256, 0.3, IOU)
+    kb, ks, kc, _ = R.process_detections(det[:, :4].numpy(), det[:, 4].numpy(), det[:, 5].numpy(), 0.3, SOFT, HARD)
+    ref = R.make_objs(kb, ks, kc, model.names, 240, 256)
+    assert len(got) == len(ref) and len(ref) >= 3
+    for a, b in zip(got, ref):
+        assert a["class_id"] == b["class_id"] and abs(a["score"] - b["score"]) <= 2e-5
+        assert all(abs(a[k] - b[k]) <= 1 for k in ("x1", "y1", "x2", "y2"))
+        assert 0 <= a["x1"] and a["x2"] <= 240 and a["y2"] <= 256              # relative to the crop
+    for bad in (dict(image_xmin=-1, image_xmax=100, image_ymin=0, image_ymax=50), dict(image_xmin=50, image_xmax=50, image_ymin=0, image_ymax=50),
+                dict(image_xmin=10, image_xmax=60, image_ymin=80, image_ymax=20)):
+        assert SFinder(model, cfg(**bad)).run() == -1
+    model.engine().close()

@@ -34,7 +34,10 @@ def _close(a, b):
 
 
 @pytest.mark.parametrize("name,imgsz,conf,iou", [("big512", 512, 0.7, 0.5), ("syn192", 192, 0.5, 0.5),
-                                                 ("galaxy", 640, 0.7, 0.5), ("rag", 256, 0.25, 0.7)])
+                                                 ("galaxy", 640, 0.7, 0.5), ("rag", 256, 0.25, 0.7),
+                                                 # conf ~ 0 at imgsz 640: nearly all 8400 anchors are candidates (> 8192: the
+                                                 # global-memory sort of nms_kernel; ultralytics' max_nms = 30000 does not bind)
+                                                 ("galaxy", 640, 0.001, 0.7)])
 def test_decode_nms_on_oracle_logits(name, imgsz, conf, iou):
     det = detector("fp32", max_imgsz=640)
     m = oracle_model()
