@@ -1717,6 +1717,293 @@ static hipError_t launch_wide(const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ 3x3 s1, 512 px x 128 ch, persistent
+// conv3x3_wide_kernel<true, 2> as ONE workgroup per CU walking the patches (patch n of a workgroup = blockIdx.x + n * gridDim.x
+// in the same XCD-aware order).  What a one-patch workgroup pays outside its stage loop -- per-workgroup records of the stamped
+// build: 2.3-3.7 us from entry to the first MFMA (the 70 KiB prologue arrives at the ~11 B/cycle a CU gets when every CU asks at
+// once), 3.2-6.9 us of epilogue, 0.7 us of store drain and 3.6-4.3 us until the next workgroup runs on the CU -- is a third of an
+// 18-stage (Cin = 128) patch.  Here the NEXT patch's prologue (bias, first halo slab, first two weight stages) is requested right
+// behind the last stage barrier and lands under the epilogue of the current patch, and there is no hand-over.
+// Two earlier persistent forms lost to the one-patch kernel (+3 %, residual layers +14 %).  The vector-memory counter is in-order:
+// a residual load issued after the next patch's 70 KiB of LDS-DMA cannot be waited for without waiting for all of that DMA, so
+// the epilogue stood still for the whole prologue.  Here the order of requests is  bias(next) -> residual(this) -> halo / weights
+// (next)  and the epilogue waits with a counted vmcnt that leaves exactly the DMA in flight; the output stores are buffer stores
+// issued by every lane (out-of-range lanes carry the out-of-range offset and are dropped by the range check), so the number of
+// operations between the DMA and the next patch's first wait is a compile-time constant too.
+template <bool SPLIT, bool RES>
+__global__ __launch_bounds__(512) void conv3x3_widep_kernel(const ConvArgs a, const int total) {
+    static_assert(!SPLIT, "fp16x3 form: not written yet (conv3x3_wide_kernel carries it)");
+    constexpr int NST = 9, TH = 16, TW = 32, NW = 8, BN = 128, PWID = TW + 2;
+    // Only waves 0-3 (one per SIMD) issue LDS-DMA.  A wave whose request does not fit the memory pipeline waits at the issue, and
+    // cannot issue MFMAs meanwhile; with every wave issuing its share at the same point of a stage both waves of a SIMD wait
+    // together and the matrix pipe idles (a slab pair WITH its requests takes 13.3-15.6 us, the last pair of a patch, which has
+    // none left to issue, 9 us).  With the requests on one wave per SIMD its partner (waves 4-7) has the pipe meanwhile.
+    constexpr int NDW = 4;                                   // requesting waves
+    constexpr int RPW = 4, MIW = 8, WPS = 2 * (NW / NDW);    // weight pieces per requesting wave and stage
+    constexpr int PR = (TH + 2) * PWID, NPC = (PR + 15) / 16, PROUNDS = (NPC + NDW - 1) / NDW;      // halo pieces per requesting wave and slab
+    constexpr int P_BYTES = PROUNDS * NDW * 1024, SLAB = BN * 64, W_BYTES = 2 * SLAB, RING = 3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const Pbuf = smem;
+    char* const Wbuf = smem + 2 * P_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int H = a.Hi, W = a.Wi;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int cpad = pad128(a.Cout);
+    const int ntn = (pad64(a.Cout) + BN - 1) / BN;
+    const int pairs = a.Cin / 64;
+    const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in0), 0, a.in0_bytes, 0x00020000);
+    const auto rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wgt32), 0, a.wgt32_bytes, 0x00020000);
+    const auto rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, (unsigned)pad64(a.Cout) * 4u, 0x00020000);
+    const unsigned out_bytes = (unsigned)((long)a.B * H * W * a.out_ct * 2);
+    const auto rso = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, out_bytes, 0x00020000);
+    const auto rsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(RES ? a.res : a.in0), 0,
+                                                       RES ? (unsigned)((long)a.B * H * W * a.res_ct * 2) : 0u, 0x00020000);
+    const int fr = lane & 15, fq = lane >> 4;
+
+    // patch v -> (image, first row / column, first channel)
+    int pb_, py0, px0, pn0;
+    auto geometry = [&](int v) {
+        const int id = xcd_remap(v, total);
+        pn0 = (id % ntn) * BN;
+        int rest = id / ntn;
+        px0 = (rest % tiles_x) * TW; rest /= tiles_x;
+        py0 = (rest % tiles_y) * TH;
+        pb_ = rest / tiles_y;
+    };
+    // developer ablation (diagnostic builds; results invalid): bit 0 no requests inside the stage loop, bit 1 no fragment reads, bit 2 no MFMAs
+    const bool no_dma = CY_STAMPS_ENABLED && (a.dbg & 1), no_rd = CY_STAMPS_ENABLED && (a.dbg & 2), no_mma = CY_STAMPS_ENABLED && (a.dbg & 4);
+    const bool dmaw = wave < NDW && !no_dma;
+    // halo piece j of a requesting wave: entries (j * NDW + wave) * 16 + (lane >> 2) of the 18 x 34 halo; the offsets are computed at
+    // the request (a dozen VALU instructions of a wave that is about to wait for the memory pipeline anyway) instead of living in
+    // ten registers next to the 128 accumulators
+    auto dma_patch = [&](int buf, int slab, int gb, int gy0, int gx0) {
+        if (!dmaw) return;
+        int l4 = lane >> 2;
+        asm volatile("" : "+v"(l4));                         // (keeps the optimiser from hoisting the ten offsets out of the stage loop)
+        const unsigned lq = (unsigned)(lane & 3);
+#pragma unroll
+        for (int j = 0; j < PROUNDS; ++j) {
+            const int r = (j * NDW + wave) * 16 + l4;
+            const int ry = (r * 1928) >> 16, rx = r - ry * PWID;       // r / 34 for r < 1024
+            const int y = gy0 + ry - 1, x = gx0 + rx - 1;
+            const unsigned q = lq ^ (unsigned)(((r >> 2) & 1) << 1);
+            const bool ok = r < PR && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+            const unsigned off = ok ? (unsigned)(((gb * H + y) * W + x) * a.in0_ct + a.in0_coff + (int)q * 8) * 2u : CY_OOB;
+            dma_piece(rs0, (lds_ptr_t*)(Pbuf + buf * P_BYTES + (j * NDW + wave) * 1024), off, (unsigned)slab * 64u);
+        }
+    };
+    // (lane-dependent LDS / weight addresses are recomputed at the top of every patch instead of living through the epilogue,
+    // where the 128 accumulators + 64 residual registers leave no room for them)
+    unsigned woff = 0;
+    auto weight_lane_offset = [&]() { const int row = wave * 32 + (lane >> 2); woff = (unsigned)(row * 64 + ((lane & 3) ^ (((row >> 2) & 1) << 1)) * 16); };
+    auto dma_stage = [&](int ring, int slab0, int u0, int n0) {      // requesting wave w: rows w*32 .. w*32+31 of both taps
+        if (!dmaw) return;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int u = u0 + t, sl = slab0 + u / 9, tap = u % 9;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                dma_piece(rsw, (lds_ptr_t*)(Wbuf + ring * W_BYTES + t * SLAB + (wave * 2 + h) * 1024), woff,
+                          (unsigned)((sl * 9 + tap) * cpad * 64 + n0 * 64 + h * 1024));
+        }
+    };
+    float* const bias_lds = reinterpret_cast<float*>(smem + 2 * P_BYTES + RING * W_BYTES);       // two slots of 1 KiB, alternating per patch
+    auto dma_bias = [&](int slot, int n0) {
+        if (wave == 0) dma_piece(rsb, (lds_ptr_t*)(bias_lds + slot * 256), lane * 16 < BN * 4 ? (unsigned)(n0 * 4 + lane * 16) : CY_OOB, 0);
+    };
+
+    f32x4 acc[4][MIW];
+    unsigned pb[8], wl = 0;
+    const int rw0 = wm * RPW * PWID;
+    auto fragment_bases = [&]() {
+        // opaque to the optimiser: otherwise it hoists these 9 registers out of the patch loop and spills around the epilogue
+        int lz = lane;
+        asm volatile("" : "+v"(lz));
+        const int r_ = lz & 15, q_ = lz >> 4;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            pb[c] = (unsigned)(rw0 * 64 + r_ * 64 + ((q_ ^ ((((c + r_ + (rw0 & 7)) >> 2) & 1) << 1)) << 4));
+        wl = (unsigned)(2 * P_BYTES + (wn * 64 + r_) * 64 + ((q_ ^ (((r_ >> 2) & 1) << 1)) << 4));
+    };
+    f16x8 xa[2][4], wb[2][4];
+    auto load_x = [&](f16x8* dst, int pbuf_off, int kh, int kw, int half) {
+        if (no_rd) return;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int mi = half * 4 + m;
+            const int base = ((mi >> 1) + kh) * PWID + (mi & 1) * 16 + kw;
+            dst[m] = *reinterpret_cast<const f16x8*>(smem + pb[base & 7] + (pbuf_off + base * 64));
+        }
+    };
+    auto load_w = [&](f16x8* dst, int wbuf_off) {
+        if (no_rd) return;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) dst[ni] = *reinterpret_cast<const f16x8*>(smem + wl + (wbuf_off + ni * 1024));
+    };
+    auto mma = [&](const f16x8* w, const f16x8* x, int half) {
+        if (no_mma) return;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                acc[ni][half * 4 + m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ni], x[m], acc[ni][half * 4 + m], 0, 0, 0);
+    };
+    auto stage_compute = [&](int st) {
+        const int u0 = 2 * st, u1 = u0 + 1, t0 = u0 % 9, t1 = u1 % 9;
+        const int p0 = (u0 / 9) * P_BYTES, p1 = (u1 / 9) * P_BYTES, w0 = (st % 3) * W_BYTES, w1 = w0 + SLAB;
+        load_w(wb[0], w0);
+        load_x(xa[0], p0, t0 / 3, t0 % 3, 0);
+        load_x(xa[1], p0, t0 / 3, t0 % 3, 1);
+        mma(wb[0], xa[0], 0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_w(wb[1], w1);
+        load_x(xa[0], p1, t1 / 3, t1 % 3, 0);
+        mma(wb[0], xa[1], 1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_x(xa[1], p1, t1 / 3, t1 % 3, 1);
+        mma(wb[1], xa[0], 0);
+        __builtin_amdgcn_sched_barrier(0);                  // the last 16 MFMAs of the stage are issued behind the stage barrier
+    };
+
+    const bool stamps = CY_STAMPS_ENABLED && (a.dbg & 64) != 0;      // diagnostic builds: phase records of the workgroup's SECOND patch
+    unsigned long long t_l0 = 0, t_l1 = 0, t_rw = 0, t_ep = 0;
+    const unsigned long long t_begin = stamps ? stamp_real() : 0;
+    // ---- first patch: prologue as in the one-patch kernel
+    int v = blockIdx.x, n = 0;
+    if (v >= total) return;
+    geometry(v);
+    weight_lane_offset();
+    dma_bias(0, pn0);
+    dma_patch(0, 0, pb_, py0, px0);
+    dma_stage(0, 0, 0, pn0);
+    dma_stage(1, 0, 2, pn0);
+    CY_WAIT_VM(WPS);
+    __builtin_amdgcn_s_barrier();
+#pragma unroll 1
+    for (;;) {
+        const int b = pb_, y0 = py0, x0 = px0, n0 = pn0;
+        const int vn = v + (int)gridDim.x;
+        const bool next = vn < total;
+        if (stamps) {
+            const unsigned long long t = stamp_real();
+            if (n == 2 && tid == 0) {                             // [0] requests + residual wait, [1] stage loop, [2] epilogue, [3] (unused)
+                unsigned long long* rec = g_wg_stamps + (size_t)(blockIdx.x % WG_STAMP_SLOTS) * 4;
+                rec[0] = t_rw - t_l1; rec[1] = t_l1 - t_l0; rec[2] = t_ep - t_rw;
+            }
+            t_l0 = t;
+        }
+        fragment_bases();
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MIW; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // The stream of stages never drains at a patch boundary: in the LAST slab pair of a patch the requests that would fetch
+        // "the next pair" fetch the first halo slab and the first two weight stages of the NEXT patch instead, at the same steady
+        // rate (a burst of the whole 70 KiB prologue holds the issuing waves for 3.3 us: the memory pipeline takes ~11 B per cycle
+        // and CU, and a wave whose request does not fit waits).  The halo offsets of the next patch replace this patch's in the same
+        // registers once its last halo request is out (stage 0 of the last pair).
+#pragma unroll 1
+        for (int cp = 0; cp < pairs; ++cp) {
+            const bool more = cp + 1 < pairs;
+            const bool chain = more || next;                     // something follows this pair
+#pragma unroll
+            for (int st = 0; st < NST; ++st) {
+                const bool has_w = st + 2 < NST || chain;
+                if (st + 2 < NST) dma_stage((st + 2) % 3, 2 * cp, 2 * (st + 2), n0);
+                else if (more) dma_stage((st + 2) % 3, 2 * cp + 2, 2 * (st + 2 - NST), n0);
+                else if (next) dma_stage((st + 2) % 3, 0, 2 * (st + 2 - NST), pn0);
+                if (st == 0) dma_patch(1, 2 * cp + 1, b, y0, x0);
+                if (st == 1 && !more && next) { geometry(vn); dma_bias((n + 1) & 1, pn0); }
+                if (st == 5 && more) dma_patch(0, 2 * cp + 2, b, y0, x0);
+                if (st == 5 && !more && next) dma_patch(0, 0, pb_, py0, px0);
+                stage_compute(st);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (st == 0 || st == 1) { CY_WAIT_VM(WPS + PROUNDS); }
+                else if (st == 5 || st == 6) { if (chain) { CY_WAIT_VM(WPS + PROUNDS); } else { CY_WAIT_VM(WPS); } }
+                else if (has_w) { CY_WAIT_VM(WPS); }
+                else { CY_WAIT_VM(0); }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                mma(wb[1], xa[1], 1);
+            }
+        }
+        if (stamps) t_l1 = stamp_real();
+        // ---- epilogue of this patch.  Stage 0 of the next patch needs nothing but what the last barrier has already published.
+        const float* bl = bias_lds + (n & 1) * 256 + wn * 64 + fq * 16;
+        float bv[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(bl + j * 4);
+            bv[j * 4] = t[0]; bv[j * 4 + 1] = t[1]; bv[j * 4 + 2] = t[2]; bv[j * 4 + 3] = t[3];
+        }
+        const int cbase = n0 + wn * 64 + fq * 16;
+        const bool chan_ok = cbase + 16 <= a.Cout;
+        // pixel index of fragment mi of this lane = pix0 + (mi >> 1) * W + (mi & 1) * 16; rows past H are uniform per fragment pair
+        const int xl = x0 + fr;
+        const unsigned pix0 = (unsigned)((b * H + y0 + wm * RPW) * W + xl);
+        const bool okx0 = xl < W && chan_ok, okx1 = xl + 16 < W && chan_ok;
+        const unsigned cb2 = (unsigned)cbase * 2u;
+        auto pixel = [&](int mi, unsigned& pix) -> bool {
+            pix = pix0 + (unsigned)((mi >> 1) * W + (mi & 1) * 16);
+            return (y0 + wm * RPW + (mi >> 1) < H) && ((mi & 1) ? okx1 : okx0);
+        };
+        f16x8 rv[MIW][2];
+        if (RES) {
+#pragma unroll
+            for (int mi = 0; mi < MIW; ++mi) {
+                unsigned pix;
+                const bool ok = pixel(mi, pix);
+                const unsigned ro = ok ? (pix * (unsigned)a.res_ct + (unsigned)a.res_coff) * 2u + cb2 : CY_OOB;
+                rv[mi][0] = __builtin_bit_cast(f16x8, load_b128(rsr, ro, 0));
+                rv[mi][1] = __builtin_bit_cast(f16x8, load_b128(rsr, ro, 16));
+            }
+            CY_WAIT_VM(0);                                       // (older than them: only the second weight stage of the next patch)
+        }
+        if (stamps) t_rw = stamp_real();
+#pragma unroll
+        for (int mi = 0; mi < MIW; ++mi) {
+            float vv[16];
+            bias_act16(acc[0][mi], acc[1][mi], acc[2][mi], acc[3][mi], bv, a.act != 0, vv);
+            if (RES) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { vv[j] += (float)rv[mi][0][j]; vv[8 + j] += (float)rv[mi][1][j]; }
+            }
+            f16x8 o0, o1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { o0[j] = (f16)vv[j]; o1[j] = (f16)vv[8 + j]; }
+            unsigned pix;
+            const bool ok = pixel(mi, pix);
+            const unsigned so = ok ? (pix * (unsigned)a.out_ct + (unsigned)a.out_coff) * 2u + cb2 : CY_OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rso, so, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), rso, so, 16, 0);
+        }
+        if (stamps) t_ep = stamp_real();
+        if (stamps && !next && tid == 0) g_wg_stamps[(size_t)(blockIdx.x % WG_STAMP_SLOTS) * 4 + 3] = t_ep - t_begin;    // [3] the workgroup's whole life
+        if (!next) break;
+        v = vn; ++n;
+    }
+}
+
+static hipError_t launch_widep(const ConvArgs& a, hipStream_t s) {
+    constexpr int PR = 18 * 34, NPC = (PR + 15) / 16, PROUNDS = (NPC + 3) / 4;
+    const size_t lds = 2 * PROUNDS * 4 * 1024 + 3 * 2 * 128 * 64 + 2048;        // halo x2, weight ring, bias x2
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_widep_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_widep_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int total = a.B * ((a.Wi + 31) / 32) * ((a.Hi + 15) / 16) * ((pad64(a.Cout) + 127) / 128);
+    static const int ncu = [] { int dev = 0, n = 256; hipGetDevice(&dev); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    const int grid = total < ncu ? total : ncu;
+    if (a.res) hipLaunchKernelGGL((conv3x3_widep_kernel<false, true>), dim3(grid), dim3(512), lds, s, a, total);
+    else hipLaunchKernelGGL((conv3x3_widep_kernel<false, false>), dim3(grid), dim3(512), lds, s, a, total);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ 1x1 (and 3x3 stride 2), pixels direct to registers
 // A 1x1 convolution has no tap reuse, so staging the pixel operand through LDS only costs: in the tiled kernels above two
 // thirds of the LDS-DMA pieces (60-180 issue cycles each) carry pixels that exactly one wave reads exactly once.  In NHWC
@@ -1726,12 +2013,14 @@ static hipError_t launch_wide(const ConvArgs& a, hipStream_t s) {
 // chunks ahead, counted vmcnt).  A wave owns MI*16 pixels x all BN = 64*NB channels of the workgroup's tile:
 //   per 64-channel K chunk and wave: NB DMA pieces + 2*MI register loads for 8*NB*MI MFMAs (NB=4, MI=2: 8 for 64).
 // Also handles the two-segment input (nearest-x2 upsample + concat) of layers 12 and 15: per-lane addresses anyway.
-template <int NB, int MI, int RING, bool K3, bool SPLIT = false>
+template <int NB, int MI, int RING, bool K3, bool SPLIT = false, int NDW = 8>
 __global__ __launch_bounds__(512, (NB * MI <= 4 && RING == 2) ? 2 : 1) void conv1x1_direct_kernel(const ConvArgs a) {
+    // NDW = number of waves that request the weight chunks (LDS-DMA): 8 = every wave its share; 4 = waves 0-3 only (one per SIMD),
+    // so that a request waiting for room in the memory pipeline holds one wave of a SIMD while its partner keeps the matrix pipe busy
     // SPLIT (fp16x3 context): three passes over the K chunks -- pixels [x_lo | x_hi | x_hi] (the low halves a.in*_lo halves behind
     // the high ones) against the packed weight chunks [w_hi | w_lo | w_hi]; scaled / split epilogue
     constexpr int NW = 8, BN = 64 * NB, BM = NW * MI * 16, W_BYTES = BN * 128, DIST = RING - 1;
-    constexpr int WPW = BN / 8 / NW, APW = 2 * MI, PER = WPW + APW;
+    constexpr int WPW = BN / 8 / NDW, APW = 2 * MI, PER = WPW + APW;     // weight pieces per requesting wave and chunk; pixel loads; both
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const bool stamps = CY_STAMPS_ENABLED && (a.dbg & 64) != 0;      // diagnostic builds: per-workgroup phase records (see the wide kernel)
     const unsigned long long t_entry = stamps ? stamp_real() : 0;
@@ -1783,12 +2072,10 @@ __global__ __launch_bounds__(512, (NB * MI <= 4 && RING == 2) ? 2 : 1) void conv
             vmask[mi] = vm;
         }
     }
-    unsigned woff[WPW];
-#pragma unroll
-    for (int j = 0; j < WPW; ++j) {
-        const int row = (j * NW + wave) * 8 + (lane >> 3);
-        woff[j] = (unsigned)((n0 + row) * 128 + ((lane & 7) ^ (row & 7)) * 16);
-    }
+    // piece j of requesting wave w = rows (j * NDW + w) * 8 .. +7 of the chunk: the lane part (row & 7 = lane >> 3) is the same for
+    // every j, the rest is uniform and rides in soffset
+    const bool reqw = wave < NDW;
+    const unsigned woff0 = (unsigned)((n0 + wave * 8 + (lane >> 3)) * 128 + ((lane & 7) ^ (lane >> 3)) * 16);
     u32x4 xa[RING][MI][2];
     int ltap = 0, lslab = 0;                                // cursor of load_a (called for c = 0, 1, 2, ... in order)
     auto load_a = [&](int slot, int cv) {                   // the uniform part of the address rides in soffset (not range-checked)
@@ -1820,9 +2107,18 @@ __global__ __launch_bounds__(512, (NB * MI <= 4 && RING == 2) ? 2 : 1) void conv
         }
     };
     auto dma_w = [&](int slot, int c) {
+        if (NDW < NW && !reqw) return;
 #pragma unroll
         for (int j = 0; j < WPW; ++j)
-            dma_piece(rsw, (lds_ptr_t*)(smem + slot * W_BYTES + (j * NW + wave) * 1024), woff[j], c * cpad * 128);
+            dma_piece(rsw, (lds_ptr_t*)(smem + slot * W_BYTES + (j * NDW + wave) * 1024), woff0, c * cpad * 128 + j * NDW * 1024);
+    };
+    // counted wait of a requesting wave: all but its n youngest requests have landed (the other waves have no LDS-DMA of their own;
+    // the loads of their pixel registers are waited for by the compiler at the use)
+    auto wait_w = [&](int n) {
+        if (NDW < NW && !reqw) return;
+        if (n == APW + 2 * PER) { CY_WAIT_VM(APW + 2 * PER); }
+        else if (n == APW + PER) { CY_WAIT_VM(APW + PER); }
+        else { CY_WAIT_VM(APW); }
     };
     f32x4 acc[NB * 4][MI];
 #pragma unroll
@@ -1868,9 +2164,9 @@ __global__ __launch_bounds__(512, (NB * MI <= 4 && RING == 2) ? 2 : 1) void conv
     for (int d = 0; d < DIST; ++d)
         if (d < chunks) { dma_w(d, d); load_a(d, d); }
     // weights of chunk 0 landed; what was requested after them may stay in flight (DIST is 2 or 3)
-    if (chunks >= DIST) { CY_WAIT_VM(APW + (DIST - 1) * PER); }
-    else if (DIST == 3 && chunks == 2) { CY_WAIT_VM(APW + PER); }
-    else { CY_WAIT_VM(APW); }
+    if (chunks >= DIST) wait_w(APW + (DIST - 1) * PER);
+    else if (DIST == 3 && chunks == 2) wait_w(APW + PER);
+    else wait_w(APW);
     __builtin_amdgcn_s_barrier();
     const unsigned long long t_loop = stamps ? stamp_real() : 0, c_loop = stamps ? stamp_now() : 0;
 #pragma unroll 1
@@ -1883,9 +2179,9 @@ __global__ __launch_bounds__(512, (NB * MI <= 4 && RING == 2) ? 2 : 1) void conv
                 compute(u);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 // weights of chunk c+1 must have landed; everything requested after them may stay in flight
-                if (c + DIST < chunks) { CY_WAIT_VM(APW + (DIST - 1) * PER); }
-                else if (DIST == 3 && c + 2 < chunks) { CY_WAIT_VM(APW + PER); }
-                else { CY_WAIT_VM(APW); }
+                if (c + DIST < chunks) wait_w(APW + (DIST - 1) * PER);
+                else if (DIST == 3 && c + 2 < chunks) wait_w(APW + PER);
+                else wait_w(APW);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
@@ -1972,18 +2268,18 @@ __global__ __launch_bounds__(512, (NB * MI <= 4 && RING == 2) ? 2 : 1) void conv
     }
 }
 
-template <int NB, int MI, int RING, bool K3, bool SPLIT = false>
+template <int NB, int MI, int RING, bool K3, bool SPLIT = false, int NDW = 8>
 static hipError_t launch_direct(const ConvArgs& a, hipStream_t s) {
     constexpr int BN = 64 * NB, BM = 8 * MI * 16;
     const size_t lds = RING * BN * 128 + 1024;             // weight ring, bias
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_direct_kernel<NB, MI, RING, K3, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_direct_kernel<NB, MI, RING, K3, SPLIT, NDW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const int M = a.B * a.Ho * a.Wo;
     const int blocks = ((M + BM - 1) / BM) * ((pad64(a.Cout) + BN - 1) / BN);
-    hipLaunchKernelGGL((conv1x1_direct_kernel<NB, MI, RING, K3, SPLIT>), dim3(blocks), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((conv1x1_direct_kernel<NB, MI, RING, K3, SPLIT, NDW>), dim3(blocks), dim3(512), lds, s, a);
     return hipGetLastError();
 }
 
@@ -2137,6 +2433,13 @@ hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s) {
         case CONV_WIDE_128: {
             static const int tps = getenv("CY_WIDE_TPS") ? atoi(getenv("CY_WIDE_TPS")) : 2;
             ConvArgs b2 = a; b2.dbg = dev_knob("CY_DBG", 0);
+            // persistent form (same arithmetic in the same order: bit-identical outputs) when every CU gets at least two patches
+            // and the output tile has whole 16-channel groups; CY_WIDE_PERSIST: 0 off, 2 regardless of the launch size (tests)
+            const int wp = env_knob("CY_WIDE_PERSIST", 1);
+            const long patches = (long)a.B * ((a.Wi + 31) / 32) * ((a.Hi + 15) / 16) * ((pad64(a.Cout) + 127) / 128);
+            // Measured per layer at batch 256: 18-stage layers (Cin 128: model.4 / model.15 bottlenecks) -4..-6 %, 36-stage ones
+            // -1.7..+1.5 %: taken for up to two slab pairs.
+            if (wp && tps == 2 && a.Cout % 16 == 0 && (wp > 1 || (patches >= 512 && a.Cin <= 128))) return launch_widep(b2, s);
             return tps == 3 ? launch_wide<2, false, 3>(b2, s) : launch_wide<2>(b2, s);
         }
         case CONV_WIDE_64: return launch_wide<1>(a, s);
@@ -2148,7 +2451,11 @@ hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s) {
             static const int v256 = getenv("CY_D256_V") ? atoi(getenv("CY_D256_V")) : 0;
             if (a.k != 3 && v256 > 0 && a.Cin <= v256) return launch_direct<4, 1, 2, false>(a, s);
             // (a 4-slot ring for this tile: 256 VGPRs with spills, 3-10 % slower)
-            return a.k == 3 ? launch_direct<4, 2, 3, true>(a2, s) : launch_direct<4, 2, 3, false>(a2, s);
+            // weight requests on 4 waves (one per SIMD) or on all 8 (CY_DIRECT_NDW forces one; same bits either way).  Measured per layer
+            // at batch 256: four requesting waves are 2-5 % faster on the strided 3x3 layers (model.5, model.7) and 1-6 % slower on the 1x1s
+            static const int ndw = env_knob("CY_DIRECT_NDW", 0);
+            if (a.k == 3) return ndw == 8 ? launch_direct<4, 2, 3, true>(a2, s) : launch_direct<4, 2, 3, true, false, 4>(a2, s);
+            return ndw == 4 ? launch_direct<4, 2, 3, false, false, 4>(a2, s) : launch_direct<4, 2, 3, false>(a2, s);
         }
         case CONV_DIRECT_128:     // strided 3x3 (model.1): 64 px per wave, so every weight fragment feeds four MFMAs (-8 % vs 32 px)
             // 1x1 with a 128-channel tile = the HBM-bound layers (model.2.cv1/cv2): two workgroups per CU (126 VGPRs, one chunk
@@ -2158,6 +2465,11 @@ hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s) {
         case CONV_GENERIC_64: return p == PREC_F16 ? launch_t<f16, 4, 1, 2>(a, s) : launch_t<float, 4, 1, 2>(a, s);
         default: return p == PREC_F16 ? launch_t<f16, 2, 2, 4>(a, s) : launch_t<float, 2, 2, 4>(a, s);
     }
+}
+
+void debug_read_wg_stamps(unsigned long long* out, int n) {      // raw per-workgroup records (n x 4) of stamped builds
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_stamps), (size_t)(n < WG_STAMP_SLOTS ? n : WG_STAMP_SLOTS) * 4 * sizeof(unsigned long long));
 }
 
 void debug_read_stamps(unsigned long long* out8, bool reset) {

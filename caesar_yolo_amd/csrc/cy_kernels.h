@@ -102,7 +102,8 @@ hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s);
 enum ConvVariant { CONV_GENERIC_128 = 0, CONV_GENERIC_64, CONV_HALO8_128, CONV_PP_64, CONV_PP_128, CONV_HALO16_128, CONV_C64_PERSIST, CONV_GENERIC_BIG, CONV_WIDE_128, CONV_DIRECT_256, CONV_DIRECT_128, CONV_WIDE_64, CONV_WIDE_DUAL, CONV_NUM_VARIANTS };
 int conv_variant(Precision p, const ConvArgs& a);          // which kernel launch_conv picks
 const char* conv_variant_name(int v);
-void debug_read_stamps(unsigned long long* out8, bool reset);   // developer diagnostics (CY_DBG=64)
+void debug_read_stamps(unsigned long long* out8, bool reset);
+void debug_read_wg_stamps(unsigned long long* out, int n);      // raw per-workgroup phase records (n x 4), stamped builds   // developer diagnostics (CY_DBG=64)
 void debug_read_pre_stamps(unsigned long long* out8, bool reset);   // phases of pre_stats_kernel (cy_preproc.hip), stamped builds only
 hipError_t launch_stem(Precision p, const StemArgs& a, hipStream_t s);
 hipError_t launch_stem_down(const StemDownArgs& a, hipStream_t s);

@@ -957,6 +957,7 @@ int cy_bottleneck64(cy_ctx* c, const void* d_in, int B, int H, int W, const floa
 
 int cy_debug_stamps(unsigned long long* out8, int reset) {
     if (!out8) return CY_ERR_ARG;
+    if (reset < 0) { debug_read_wg_stamps(out8, -reset); return CY_OK; }      // raw per-workgroup records: out8 holds (-reset) x 4 values
     if (reset >= 2) debug_read_pre_stamps(out8, reset == 3);       // 2 / 3: the statistics kernel's phase stamps (read / read + reset)
     else debug_read_stamps(out8, reset != 0);
     return CY_OK;

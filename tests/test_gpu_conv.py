@@ -213,3 +213,26 @@ def test_fused_bottleneck64(B, H, W, shortcut):
     sc = max(1.0, float(ref.abs().max()))
     err = float((got - ref).abs().max())
     assert err <= 4e-3 * sc, "max abs err %.3e (scale %.2f)" % (err, sc)
+
+
+@pytest.mark.parametrize("case", [(70, 64, 64, 128, 128, True), (40, 64, 64, 128, 128, False), (33, 40, 60, 128, 256, True), (21, 52, 64, 256, 192, True),
+                                  (300, 32, 32, 256, 256, False), (9, 64, 96, 64, 128, True), (2, 16, 32, 128, 128, False)])
+def test_wide_persistent_kernel_is_bit_identical(case, monkeypatch):
+    """conv3x3_widep_kernel (one workgroup per CU walking the patches, the next patch's prologue requested behind the last stage
+    barrier, counted vmcnt waits around the epilogue) does the arithmetic of the one-patch wide kernel in the same order: same bits,
+    on 1..3 patches per workgroup, odd and even counts, ragged rows / columns, a half-empty second channel tile, with and without
+    the residual input -- and repeatably (the hand-overs rest on counted waits)."""
+    B, H, W, Cin, Cout, use_res = case
+    det = detector("fp16", max_batch=4)
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    xd = torch.randn((B, H, W, Cin), generator=g).half().cuda()
+    rd = torch.randn((B, H, W, Cout), generator=g).half().cuda() if use_res else None
+    w = (torch.randn((Cout, Cin, 3, 3), generator=g) / (Cin * 9) ** 0.5).numpy()
+    b = (torch.randn((Cout,), generator=g) * 0.1).numpy()
+    monkeypatch.setenv("CY_WIDE_PERSIST", "0")
+    ref = det.conv_bn_silu(xd, w, b, 3, 1, True, rd).clone()
+    monkeypatch.setenv("CY_WIDE_PERSIST", "2")
+    for _ in range(6):
+        got = det.conv_bn_silu(xd, w, b, 3, 1, True, rd)
+        torch.cuda.synchronize()
+        assert torch.equal(ref, got)
