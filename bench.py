@@ -160,7 +160,7 @@ def kernel_family(n):
     import re
     n = n.replace(" ", "")
     base = None
-    for b in ("conv3x3_wide_kernel", "conv1x1_direct_kernel", "conv_igemm_kernel", "conv3x3_halo2_kernel", "conv3x3_halo_kernel",
+    for b in ("conv3x3_widep_kernel", "conv3x3_wide_kernel", "conv1x1_direct_kernel", "conv_igemm_kernel", "conv3x3_halo2_kernel", "conv3x3_halo_kernel",
               "conv3x3_pp_kernel", "conv3x3_c64_kernel", "stem_down2_kernel", "stem_down_kernel", "stem_mfma_kernel", "pool5_kernel"):
         if b in n:
             base = b

@@ -1730,8 +1730,18 @@ static hipError_t launch_wide(const ConvArgs& a, hipStream_t s) {
 // (next)  and the epilogue waits with a counted vmcnt that leaves exactly the DMA in flight; the output stores are buffer stores
 // issued by every lane (out-of-range lanes carry the out-of-range offset and are dropped by the range check), so the number of
 // operations between the DMA and the next patch's first wait is a compile-time constant too.
-template <bool SPLIT, bool RES>
-__global__ __launch_bounds__(512) void conv3x3_widep_kernel(const ConvArgs a, const int total) {
+// STRIP form (STRIP = halo pieces per requesting wave and slab: 10 for maps up to 62 px wide, 12 up to 95): a workgroup owns 512
+// consecutive ENTRIES of the batch flattened to one dimension -- image after image, row after row, with ONE zero entry after each
+// row and one zero row after each image (row stride RS = W + 1, image stride IS = (H + 1) * RS).  Zero padding of a 3x3 filter is
+// then just those shared zero entries: tap (kh, kw) of entry e is entry e + (kh - 1) * RS + (kw - 1) for EVERY entry, so any 16
+// consecutive entries are an MFMA pixel fragment and a map of any size is covered with (RS / W) * ((H + 1) / H) - 1 idle lanes
+// (80 x 80: 2.5 %, 40 x 40: 5 %, 20 x 20: 10 %, 52 x 64 of a ragged tile: 3.5 %) instead of the 17-61 % that 16 x 32-pixel patches
+// waste on 80 / 40 / 20-px maps.  Price: a halo of RS + 1 entries on both sides (676 staged entries for 80-px rows against 612).
+struct StripGeo { int RS, IS, NE; unsigned long long mRS, mIS; };      // NE = B * IS entries; m* = ceil(2^40 / divisor)
+__device__ __forceinline__ int strip_div(int e, unsigned long long m) { return (int)(((unsigned long long)(unsigned)e * m) >> 40); }
+
+template <bool SPLIT, bool RES, int STRIP = 0>
+__global__ __launch_bounds__(512) void conv3x3_widep_kernel(const ConvArgs a, const int total, const StripGeo sg) {
     static_assert(!SPLIT, "fp16x3 form: not written yet (conv3x3_wide_kernel carries it)");
     constexpr int NST = 9, TH = 16, TW = 32, NW = 8, BN = 128, PWID = TW + 2;
     // Only waves 0-3 (one per SIMD) issue LDS-DMA.  A wave whose request does not fit the memory pipeline waits at the issue, and
@@ -1740,7 +1750,7 @@ __global__ __launch_bounds__(512) void conv3x3_widep_kernel(const ConvArgs a, co
     // none left to issue, 9 us).  With the requests on one wave per SIMD its partner (waves 4-7) has the pipe meanwhile.
     constexpr int NDW = 4;                                   // requesting waves
     constexpr int RPW = 4, MIW = 8, WPS = 2 * (NW / NDW);    // weight pieces per requesting wave and stage
-    constexpr int PR = (TH + 2) * PWID, NPC = (PR + 15) / 16, PROUNDS = (NPC + NDW - 1) / NDW;      // halo pieces per requesting wave and slab
+    constexpr int PR = (TH + 2) * PWID, NPC = (PR + 15) / 16, PROUNDS = STRIP ? STRIP : (NPC + NDW - 1) / NDW;      // halo pieces per requesting wave and slab
     constexpr int P_BYTES = PROUNDS * NDW * 1024, SLAB = BN * 64, W_BYTES = 2 * SLAB, RING = 3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const Pbuf = smem;
@@ -1768,6 +1778,7 @@ __global__ __launch_bounds__(512) void conv3x3_widep_kernel(const ConvArgs a, co
         const int id = xcd_remap(v, total);
         pn0 = (id % ntn) * BN;
         int rest = id / ntn;
+        if constexpr (STRIP != 0) { px0 = rest * 512; py0 = 0; pb_ = 0; return; }       // px0 = first entry of the strip
         px0 = (rest % tiles_x) * TW; rest /= tiles_x;
         py0 = (rest % tiles_y) * TH;
         pb_ = rest / tiles_y;
@@ -1783,6 +1794,24 @@ __global__ __launch_bounds__(512) void conv3x3_widep_kernel(const ConvArgs a, co
         int l4 = lane >> 2;
         asm volatile("" : "+v"(l4));                         // (keeps the optimiser from hoisting the ten offsets out of the stage loop)
         const unsigned lq = (unsigned)(lane & 3);
+        if constexpr (STRIP != 0) {
+            // staged entry le of the strip = entry gx0 - RS - 1 + le of the flattened batch -> (image, row, column) or a zero
+            const int hl = 514 + 2 * sg.RS;
+#pragma unroll
+            for (int j = 0; j < PROUNDS; ++j) {
+                const int le = (j * NDW + wave) * 16 + l4;
+                const int e = gx0 - sg.RS - 1 + le;
+                const bool in = le < hl && (unsigned)e < (unsigned)sg.NE;
+                const int ec = in ? e : 0;
+                const int bb = strip_div(ec, sg.mIS), r = ec - bb * sg.IS;
+                const int y = strip_div(r, sg.mRS), x = r - y * sg.RS;
+                const unsigned q = lq ^ (unsigned)(((le >> 2) & 1) << 1);
+                const bool ok = in && y < H && x < W;
+                const unsigned off = ok ? (unsigned)(((bb * H + y) * W + x) * a.in0_ct + a.in0_coff + (int)q * 8) * 2u : CY_OOB;
+                dma_piece(rs0, (lds_ptr_t*)(Pbuf + buf * P_BYTES + (j * NDW + wave) * 1024), off, (unsigned)slab * 64u);
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < PROUNDS; ++j) {
             const int r = (j * NDW + wave) * 16 + l4;
@@ -1815,16 +1844,26 @@ __global__ __launch_bounds__(512) void conv3x3_widep_kernel(const ConvArgs a, co
     };
 
     f32x4 acc[4][MIW];
-    unsigned pb[8], wl = 0;
+    unsigned pb[STRIP ? 9 : 8], wl = 0;
     const int rw0 = wm * RPW * PWID;
     auto fragment_bases = [&]() {
         // opaque to the optimiser: otherwise it hoists these 9 registers out of the patch loop and spills around the epilogue
         int lz = lane;
         asm volatile("" : "+v"(lz));
         const int r_ = lz & 15, q_ = lz >> 4;
+        if constexpr (STRIP != 0) {
+            // strip form: one lane base per TAP -- staged row of (tap, fragment 0) = kh * RS + kw + wm * 128 + fr; fragment m is 16 m rows
+            // (1 KiB, same swizzle phase) further on
 #pragma unroll
-        for (int c = 0; c < 8; ++c)
-            pb[c] = (unsigned)(rw0 * 64 + r_ * 64 + ((q_ ^ ((((c + r_ + (rw0 & 7)) >> 2) & 1) << 1)) << 4));
+            for (int t = 0; t < 9; ++t) {
+                const int R0 = (t / 3) * sg.RS + (t % 3) + wm * 128 + r_;
+                pb[t] = (unsigned)(R0 * 64 + ((q_ ^ (((R0 >> 2) & 1) << 1)) << 4));
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                pb[c] = (unsigned)(rw0 * 64 + r_ * 64 + ((q_ ^ ((((c + r_ + (rw0 & 7)) >> 2) & 1) << 1)) << 4));
+        }
         wl = (unsigned)(2 * P_BYTES + (wn * 64 + r_) * 64 + ((q_ ^ (((r_ >> 2) & 1) << 1)) << 4));
     };
     f16x8 xa[2][4], wb[2][4];
@@ -1833,8 +1872,12 @@ __global__ __launch_bounds__(512) void conv3x3_widep_kernel(const ConvArgs a, co
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const int mi = half * 4 + m;
-            const int base = ((mi >> 1) + kh) * PWID + (mi & 1) * 16 + kw;
-            dst[m] = *reinterpret_cast<const f16x8*>(smem + pb[base & 7] + (pbuf_off + base * 64));
+            if constexpr (STRIP != 0) {
+                dst[m] = *reinterpret_cast<const f16x8*>(smem + pb[kh * 3 + kw] + (pbuf_off + mi * 1024));
+            } else {
+                const int base = ((mi >> 1) + kh) * PWID + (mi & 1) * 16 + kw;
+                dst[m] = *reinterpret_cast<const f16x8*>(smem + pb[base & 7] + (pbuf_off + base * 64));
+            }
         }
     };
     auto load_w = [&](f16x8* dst, int wbuf_off) {
@@ -1946,9 +1989,29 @@ __global__ __launch_bounds__(512) void conv3x3_widep_kernel(const ConvArgs a, co
         const unsigned pix0 = (unsigned)((b * H + y0 + wm * RPW) * W + xl);
         const bool okx0 = xl < W && chan_ok, okx1 = xl + 16 < W && chan_ok;
         const unsigned cb2 = (unsigned)cbase * 2u;
+        // strip form: entry of (fragment 0, this lane) -> (image, row, column) by division, the following fragments by stepping 16 entries
+        // (RS > 16: at most one row wrap per step)
+        int sb = 0, sy = 0, sx = 0;
+        if constexpr (STRIP != 0) {
+            const int e = x0 + wm * 128 + fr;
+            const int ec = e < sg.NE ? e : 0;
+            sb = strip_div(ec, sg.mIS);
+            const int r = ec - sb * sg.IS;
+            sy = strip_div(r, sg.mRS); sx = r - sy * sg.RS;
+            if (e >= sg.NE) sb = a.B;                                  // past the last image
+        }
         auto pixel = [&](int mi, unsigned& pix) -> bool {
-            pix = pix0 + (unsigned)((mi >> 1) * W + (mi & 1) * 16);
-            return (y0 + wm * RPW + (mi >> 1) < H) && ((mi & 1) ? okx1 : okx0);
+            if constexpr (STRIP != 0) {
+                int bb = sb, yy = sy, xx = sx + 16 * mi;
+                const int rows = strip_div(xx, sg.mRS);                // whole rows stepped over (RS >= 18: at most 8 for the wave's 128 entries)
+                xx -= rows * sg.RS; yy += rows;
+                if (yy > H) { yy -= H + 1; ++bb; }                     // (an image has >= 324 entries: at most one image boundary)
+                pix = (unsigned)((bb * H + yy) * W + xx);
+                return bb < a.B && yy < H && xx < W && chan_ok;
+            } else {
+                pix = pix0 + (unsigned)((mi >> 1) * W + (mi & 1) * 16);
+                return (y0 + wm * RPW + (mi >> 1) < H) && ((mi & 1) ? okx1 : okx0);
+            }
         };
         f16x8 rv[MIW][2];
         if (RES) {
@@ -1987,21 +2050,39 @@ __global__ __launch_bounds__(512) void conv3x3_widep_kernel(const ConvArgs a, co
     }
 }
 
-static hipError_t launch_widep(const ConvArgs& a, hipStream_t s) {
-    constexpr int PR = 18 * 34, NPC = (PR + 15) / 16, PROUNDS = (NPC + 3) / 4;
+template <int STRIP>
+static hipError_t launch_widep_t(const ConvArgs& a, hipStream_t s, int total, const StripGeo& sg) {
+    constexpr int PR = 18 * 34, NPC = (PR + 15) / 16, PROUNDS = STRIP ? STRIP : (NPC + 3) / 4;
     const size_t lds = 2 * PROUNDS * 4 * 1024 + 3 * 2 * 128 * 64 + 2048;        // halo x2, weight ring, bias x2
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_widep_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_widep_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_widep_kernel<false, false, STRIP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_widep_kernel<false, true, STRIP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    const int total = a.B * ((a.Wi + 31) / 32) * ((a.Hi + 15) / 16) * ((pad64(a.Cout) + 127) / 128);
     static const int ncu = [] { int dev = 0, n = 256; hipGetDevice(&dev); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
     const int grid = total < ncu ? total : ncu;
-    if (a.res) hipLaunchKernelGGL((conv3x3_widep_kernel<false, true>), dim3(grid), dim3(512), lds, s, a, total);
-    else hipLaunchKernelGGL((conv3x3_widep_kernel<false, false>), dim3(grid), dim3(512), lds, s, a, total);
+    if (a.res) hipLaunchKernelGGL((conv3x3_widep_kernel<false, true, STRIP>), dim3(grid), dim3(512), lds, s, a, total, sg);
+    else hipLaunchKernelGGL((conv3x3_widep_kernel<false, false, STRIP>), dim3(grid), dim3(512), lds, s, a, total, sg);
     return hipGetLastError();
+}
+
+static hipError_t launch_widep(const ConvArgs& a, hipStream_t s) {
+    const int total = a.B * ((a.Wi + 31) / 32) * ((a.Hi + 15) / 16) * ((pad64(a.Cout) + 127) / 128);
+    return launch_widep_t<0>(a, s, total, StripGeo{});
+}
+
+// idle share of the MFMA lanes of the 2-D patch form (16 x 32-pixel patches) and of the strip form on an H x W map
+static double wide2d_cover(int H, int W) { return (double)((H + 15) / 16 * 16) * ((W + 31) / 32 * 32) / ((double)H * W); }
+static double strip_cover(int H, int W) { return (double)(H + 1) * (W + 1) / ((double)H * W); }
+static bool strip_fits(const ConvArgs& a) { return a.Wi >= 17 && a.Hi >= 17 && a.Wi <= 126 && a.Cout % 16 == 0 && (long)a.B * (a.Hi + 1) * (a.Wi + 1) < (1L << 22); }
+
+static hipError_t launch_strip(const ConvArgs& a, hipStream_t s) {
+    StripGeo sg;
+    sg.RS = a.Wi + 1; sg.IS = (a.Hi + 1) * sg.RS; sg.NE = a.B * sg.IS;
+    sg.mRS = ((1ull << 40) + sg.RS - 1) / sg.RS; sg.mIS = ((1ull << 40) + sg.IS - 1) / sg.IS;
+    const int total = ((sg.NE + 511) / 512) * ((pad64(a.Cout) + 127) / 128);
+    return a.Wi <= 62 ? launch_widep_t<10>(a, s, total, sg) : launch_widep_t<12>(a, s, total, sg);
 }
 
 // ------------------------------------------------------------------------------------------------ 1x1 (and 3x3 stride 2), pixels direct to registers
@@ -2322,7 +2403,8 @@ static const char* const kVariantNames[CONV_NUM_VARIANTS] = {
     "conv3x3_c64_kernel<64|32> 3x3 s1 persistent, Cin 64 or 32", "conv_igemm_kernel<4,2,4,3> generic 256x128, 3-slab ring",
     "conv3x3_wide_kernel 3x3 s1 16x32px x128ch, K slabs of 32",
     "conv1x1_direct_kernel<4,2> 1x1 256px x256ch, pixels to regs", "conv1x1_direct_kernel<2,2> 1x1 256px x128ch, pixels to regs",
-    "conv3x3_wide_kernel<WN=1> 3x3 s1 16x32px x64ch", "conv3x3_wide_kernel<dual> 3x3 s1 2 images x 16x16px x128ch"};
+    "conv3x3_wide_kernel<WN=1> 3x3 s1 16x32px x64ch", "conv3x3_wide_kernel<dual> 3x3 s1 2 images x 16x16px x128ch",
+    "conv3x3_widep_kernel<strip> 3x3 s1 512 flattened px x128ch, persistent"};
 const char* conv_variant_name(int v) { return v >= 0 && v < CONV_NUM_VARIANTS ? kVariantNames[v] : "?"; }
 
 static bool s2_direct() { static const int v = getenv("CY_S2_DIRECT") ? atoi(getenv("CY_S2_DIRECT")) : 1; return v != 0; }
@@ -2376,6 +2458,13 @@ int conv_variant(Precision p, const ConvArgs& a) {
         if (force == 5) return CONV_PP_128;
         if (force == 4 || force == 43) return CONV_HALO16_128;
         static const int wide = getenv("CY_WIDE") ? atoi(getenv("CY_WIDE")) : 1;
+        // strip form of the wide kernel (maps flattened to one dimension) where 16 x 32-pixel patches would leave > 4 % more of the MFMA
+        // lanes idle: 80 / 40 / 20-px maps of 640-px inputs, 52 x 64 / 26 x 32 maps of the ragged 416 x 512 tiles.  CY_STRIP: 0 off,
+        // 2 regardless of the launch size (tests); read per call.
+        const int strip = env_knob("CY_STRIP", 1);
+        if (wide && strip && a.wgt32 && strip_fits(a) && strip_cover(a.Hi, a.Wi) + 0.04 < wide2d_cover(a.Hi, a.Wi) &&
+            (strip > 1 || Bv * (long)(a.Hi + 1) * (a.Wi + 1) / 512 * ((pad64(a.Cout) + 127) / 128) >= 200))      // (about one strip per CU)
+            return CONV_STRIP_128;
         const int wpad = (a.Wi + 31) / 32 * 32;
         if (wide && a.wgt32 && (wpad - a.Wi) * 8 <= a.Wi) return CONV_WIDE_128;     // <= 12.5 % of the patch columns idle
         const int dual = getenv("CY_WIDE_DUAL") ? atoi(getenv("CY_WIDE_DUAL")) : 1;      // read per call: 2 forces it (tests)
@@ -2442,6 +2531,7 @@ hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s) {
             if (wp && tps == 2 && a.Cout % 16 == 0 && (wp > 1 || (patches >= 512 && a.Cin <= 128))) return launch_widep(b2, s);
             return tps == 3 ? launch_wide<2, false, 3>(b2, s) : launch_wide<2>(b2, s);
         }
+        case CONV_STRIP_128: return launch_strip(a, s);
         case CONV_WIDE_64: return launch_wide<1>(a, s);
         case CONV_WIDE_DUAL: return launch_wide<2, true>(a, s);
         case CONV_DIRECT_256: {

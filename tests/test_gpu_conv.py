@@ -236,3 +236,35 @@ def test_wide_persistent_kernel_is_bit_identical(case, monkeypatch):
         got = det.conv_bn_silu(xd, w, b, 3, 1, True, rd)
         torch.cuda.synchronize()
         assert torch.equal(ref, got)
+
+
+@pytest.mark.parametrize("case", [(5, 80, 80, 128, 128, True), (7, 40, 40, 256, 256, False), (9, 20, 20, 512, 512, True), (3, 52, 64, 128, 128, True),
+                                  (4, 26, 32, 256, 192, False), (2, 33, 47, 64, 128, True), (1, 17, 95, 128, 144, False), (13, 20, 20, 128, 128, False),
+                                  (2, 100, 126, 64, 128, True)])
+def test_strip_form_of_the_wide_kernel(case, monkeypatch):
+    """conv3x3_widep_kernel<strip>: the batch flattened to one dimension with one shared zero entry per row and one zero row per image
+    (any map size from 17 px on; the 80 / 40 / 20-px maps of 640-px inputs, the 52 x 64 / 26 x 32 maps of ragged tiles), forced on
+    these small launches: against F.conv2d on fp16-rounded inputs, and bit-for-bit repeatable.  Cases: last strip partly past the
+    batch, rows shorter and longer than a 16-entry fragment step, both halo sizes (10 / 12 pieces), half-empty channel tile."""
+    monkeypatch.setenv("CY_STRIP", "2")
+    B, H, W, Cin, Cout, use_res = case
+    det = detector("fp16", max_batch=4)
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn((B, Cin, H, W), generator=g).half().float()
+    w = (torch.randn((Cout, Cin, 3, 3), generator=g) / (Cin * 9) ** 0.5).half().float()
+    b = torch.randn((Cout,), generator=g) * 0.1
+    y = F.silu(F.conv2d(x, w, b, padding=1))
+    res = None
+    if use_res:
+        res = torch.randn(y.shape, generator=g).half().float()
+        y = y + res
+    xd = x.permute(0, 2, 3, 1).contiguous().half().cuda()
+    rd = res.permute(0, 2, 3, 1).contiguous().half().cuda() if use_res else None
+    out = det.conv_bn_silu(xd, w.numpy(), b.numpy(), 3, 1, True, rd)
+    torch.cuda.synchronize()
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    scale = max(float(y.abs().max()), 1.0)
+    err = float((got - y).abs().max())
+    assert err <= 4e-3 * scale, "max abs err %.3e (scale %.2f)" % (err, scale)
+    for _ in range(4):
+        assert torch.equal(out, det.conv_bn_silu(xd, w.numpy(), b.numpy(), 3, 1, True, rd))
