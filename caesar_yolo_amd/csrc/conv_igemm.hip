@@ -2155,11 +2155,22 @@ __global__ __launch_bounds__(512, (NB * MI <= 4 && RING == 2) ? 2 : 1) void conv
     }
     // piece j of requesting wave w = rows (j * NDW + w) * 8 .. +7 of the chunk: the lane part (row & 7 = lane >> 3) is the same for
     // every j, the rest is uniform and rides in soffset
+    // developer ablation (diagnostic builds; results invalid): bit 0 no weight requests in the loop, bit 1 no weight fragment reads,
+    // bit 2 no MFMAs, bit 3 no pixel loads in the loop.  Round 3, 1024 -> 256 channels on 64 x 64 maps at batch 256, us per K chunk in a
+    // stamped build: everything 2.57 | no weight requests 2.42 | no fragment reads 2.34 | no MFMAs 1.70 | no pixel loads 1.59 | MFMAs +
+    // fragment reads 1.35 | MFMAs alone 1.16 | barriers alone 0.33.  The loop waits for its operands: per chunk a workgroup fetches
+    // 32 KB of pixels and 32 KB of weights, and 64 KB per ~3900 cycles = 16-17 B per cycle and CU is the rate every fetch-heavy kernel
+    // of this library tops out at (the wide kernel's requests alone: 15.7 B per cycle).  More requests in flight do not help -- touching
+    // the pixel lines 1 / 2 / 4 chunks ahead of the register ring (4-byte LDS-DMA into a dump area) made every 1x1 layer 9-21 % SLOWER --
+    // only fewer bytes per MFMA would, and the 256 px x 256 ch tile is the largest the 128 accumulator registers of 8 waves allow.
+    const bool no_dma = CY_STAMPS_ENABLED && (a.dbg & 1), no_rd = CY_STAMPS_ENABLED && (a.dbg & 2), no_mma = CY_STAMPS_ENABLED && (a.dbg & 4),
+               no_px = CY_STAMPS_ENABLED && (a.dbg & 8);
     const bool reqw = wave < NDW;
     const unsigned woff0 = (unsigned)((n0 + wave * 8 + (lane >> 3)) * 128 + ((lane & 7) ^ (lane >> 3)) * 16);
     u32x4 xa[RING][MI][2];
     int ltap = 0, lslab = 0;                                // cursor of load_a (called for c = 0, 1, 2, ... in order)
     auto load_a = [&](int slot, int cv) {                   // the uniform part of the address rides in soffset (not range-checked)
+        if (no_px) return;
         int lo = 0;
         const int c = SPLIT ? x3_chunk(cv, pchunks, lo) : cv;           // physical chunk (the weights are packed per virtual chunk)
         const unsigned lo0 = SPLIT && lo ? (unsigned)a.in0_lo * 2u : 0u, lo1 = SPLIT && lo ? (unsigned)a.in1_lo * 2u : 0u;
@@ -2188,7 +2199,7 @@ __global__ __launch_bounds__(512, (NB * MI <= 4 && RING == 2) ? 2 : 1) void conv
         }
     };
     auto dma_w = [&](int slot, int c) {
-        if (NDW < NW && !reqw) return;
+        if ((NDW < NW && !reqw) || no_dma) return;
 #pragma unroll
         for (int j = 0; j < WPW; ++j)
             dma_piece(rsw, (lds_ptr_t*)(smem + slot * W_BYTES + (j * NDW + wave) * 1024), woff0, c * cpad * 128 + j * NDW * 1024);
@@ -2211,6 +2222,7 @@ __global__ __launch_bounds__(512, (NB * MI <= 4 && RING == 2) ? 2 : 1) void conv
         // 2*NB groups of (4 weight fragments, 4*MI MFMAs); the fragments of group i+1 are read before the MFMAs of group i
         f16x8 wb[2][4];
         auto load_wb = [&](f16x8* dst, int gi) {
+            if (no_rd) return;
             const int kk = gi / NB, g = gi % NB, qf = fq + 4 * kk;
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
@@ -2223,6 +2235,7 @@ __global__ __launch_bounds__(512, (NB * MI <= 4 && RING == 2) ? 2 : 1) void conv
         for (int gi = 0; gi < 2 * NB; ++gi) {
             const int kk = gi / NB, g = gi % NB;
             if (gi + 1 < 2 * NB) load_wb(wb[(gi + 1) & 1], gi + 1);
+            if (!no_mma)
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
 #pragma unroll

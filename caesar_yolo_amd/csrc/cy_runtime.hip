@@ -1184,6 +1184,14 @@ int cy_detect_flush(cy_ctx* c, void* stream) {
     return CY_OK;
 }
 
+int cy_compact_records(const float* d_gathered, const long long* d_perm, int T, int row_floats, int* d_hdr, float* d_out, void* stream) {
+    if (!d_gathered || !d_perm || !d_hdr || !d_out || T < 1 || row_floats != CY_MAX_DET * CY_DET_STRIDE + 3)
+        return fail(nullptr, CY_ERR_ARG, "bad arguments");
+    const hipError_t e = launch_compact_records(d_gathered, d_perm, T, row_floats, d_hdr, d_out, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(nullptr, CY_ERR_HIP, hipGetErrorString(e));
+    return CY_OK;
+}
+
 int cy_detect_counters(cy_ctx* c, long long* out4, int reset) {
     if (!c || !c->loaded || !out4) return fail(c, CY_ERR_ARG, "bad arguments");
     int h[4] = {0, 0, 0, 0};

@@ -333,4 +333,57 @@ hipError_t launch_iou_merge(const MergeArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ gathered records -> merge input
+// After the all-gather rank 0 holds [R ranks][rows][300*6 + 3] floats (detections | count | status | tile id).  The cross-tile merge
+// wants the valid detections in tile-id order on the host.  Two launches compact them on device, so that only the detections cross
+// PCIe: (1) one workgroup walks the tiles in tile-id order (perm[t] = row of tile t), writes count (0 for a rejected tile) and status
+// per tile and the exclusive prefix of the counts, (2) one workgroup per tile copies its rows to out[prefix[t] ..].
+__global__ __launch_bounds__(1024) void records_scan_kernel(const float* __restrict__ g, const long long* __restrict__ perm, int T, int stride,
+                                                            int* __restrict__ hdr) {        // hdr: [T] counts | [T] status | [T] prefix | total
+    __shared__ int part[1024];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < T; base += 1024) {
+        const int t = base + (int)threadIdx.x;
+        int cnt = 0;
+        if (t < T) {
+            const float* row = g + perm[t] * (long long)stride;
+            const int st = (int)row[stride - 2];
+            cnt = st == 0 ? (int)row[stride - 3] : 0;
+            cnt = cnt < 0 ? 0 : (cnt > 300 ? 300 : cnt);
+            hdr[t] = cnt; hdr[T + t] = st;
+        }
+        part[threadIdx.x] = cnt;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {                   // inclusive scan of the 1024 counts of this round
+            const int v = threadIdx.x >= (unsigned)d ? part[threadIdx.x - d] : 0;
+            __syncthreads();
+            part[threadIdx.x] += v;
+            __syncthreads();
+        }
+        if (t < T) hdr[2 * T + t] = carry + part[threadIdx.x] - cnt;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += part[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) hdr[3 * T] = carry;
+}
+
+__global__ __launch_bounds__(64) void records_copy_kernel(const float* __restrict__ g, const long long* __restrict__ perm, int T, int stride,
+                                                          const int* __restrict__ hdr, float* __restrict__ out) {
+    const int t = blockIdx.x;
+    const int n = hdr[t] * 6;
+    const float* row = g + perm[t] * (long long)stride;
+    float* dst = out + (long long)hdr[2 * T + t] * 6;
+    for (int i = threadIdx.x; i < n; i += 64) dst[i] = row[i];
+}
+
+hipError_t launch_compact_records(const float* g, const long long* perm, int T, int stride, int* hdr, float* out, hipStream_t s) {
+    if (T < 1 || stride < 9) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(records_scan_kernel, dim3(1), dim3(1024), 0, s, g, perm, T, stride, hdr);
+    hipLaunchKernelGGL(records_copy_kernel, dim3(T), dim3(64), 0, s, g, perm, T, stride, (const int*)hdr, out);
+    return hipGetLastError();
+}
+
 }  // namespace cy

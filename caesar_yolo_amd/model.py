@@ -249,6 +249,12 @@ class HipDetector(object):
         """Order the current stream behind every batch queued by detect_tiles (they run on internal side streams)."""
         self._chk(self.lib.cy_detect_flush(self.ctx, self._stream()))
 
+    def compact_records(self, gathered, perm, hdr, out):
+        """gathered [R, rows, 1803] fp32, perm [T] int64 (row of tile t over all ranks) -> hdr [3T+1] int32, out [T*300*6] fp32 (device)."""
+        T = int(perm.shape[0])
+        self._chk(self.lib.cy_compact_records(self._p(gathered), self._p(perm), T, int(gathered.shape[-1]), self._p(hdr), self._p(out),
+                                              self._stream()))
+
     def fence(self):
         """Work queued on the current stream since the last detect_tiles call (an upload into a mosaic buffer already in use, a
         memset of an output buffer) is ordered before the next call's internal streams (cy_detect_fence)."""

@@ -58,21 +58,28 @@ with open(os.path.join(P, tag + "_final_summary.md"), "w") as fp:
         fp.write("`roofline.achieved` = the launches of the full batches (main lane: %d launches in the profiled step); with the launches of the "
                  "small-batch lane, which run on another stream beside them: %.1f TFLOP/s over %s launches; with the GPU to itself: %s TFLOP/s.\n\n"
                  % (r["launches"], r["achieved_all_launches"], r.get("launches_all"), ("%.1f" % r["achieved_exclusive"]) if r.get("achieved_exclusive") else "n/a"))
-    # the dominant kernel's launches in the rocprofv3 trace, split the same way (full batches launch >= 1000 workgroups)
+    # the dominant kernel's launches in the rocprofv3 trace, split the same way (full batches launch >= 1000 workgroups; the
+    # persistent form of the same kernel -- one workgroup per CU -- runs the 18-stage layers of the full batches)
     tr = glob.glob(os.path.join(G, tag + "_ktrace", "*", "*kernel_trace.csv"))
     if tr:
-        main, small = [0, 0.0], [0, 0.0]
+        main, small, pers = [0, 0.0], [0, 0.0], [0, 0.0]
         for row in csv.DictReader(open(max(tr, key=os.path.getmtime))):
-            if "conv3x3_wide_kernel<true, 2, false, 2>" not in row["Kernel_Name"]:
+            n = row["Kernel_Name"].replace(" ", "")
+            d = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3
+            if "conv3x3_widep_kernel<false,false,0>" in n or "conv3x3_widep_kernel<false,true,0>" in n:
+                pers[0] += 1; pers[1] += d
+                continue
+            if "conv3x3_wide_kernel<true,2,false,2,false>" not in n:
                 continue
             wgs = int(row.get("Grid_Size_X", row.get("Grid_Size", 0))) // 512
-            d = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3
             tgt = main if wgs >= 1000 else small
             tgt[0] += 1; tgt[1] += d
         if main[0]:
-            fp.write("Same split in the rocprofv3 kernel trace below (`conv3x3_wide_kernel<true, 2, false, 2>`): full batches %d launches, avg %.1f us; "
-                     "small-batch lane %d launches, avg %.1f us (bench.py's hipEvent average over the full batches: %.1f us).\n\n"
-                     % (main[0], main[1] / main[0], small[0], (small[1] / small[0]) if small[0] else 0.0, 1e3 * r["avg_launch_ms"]))
+            fp.write("Same split in the rocprofv3 kernel trace below: `conv3x3_wide_kernel<true, 2, false, 2, false>` full batches %d launches, avg %.1f us; "
+                     "its persistent form `conv3x3_widep_kernel<false, *, 0>` (18-stage layers of the full batches) %d launches, avg %.1f us; both together "
+                     "%d launches, avg %.1f us; small-batch lane %d launches, avg %.1f us (bench.py's hipEvent average over the full batches, both forms: %.1f us).\n\n"
+                     % (main[0], main[1] / main[0], pers[0], (pers[1] / pers[0]) if pers[0] else 0.0, main[0] + pers[0],
+                        (main[1] + pers[1]) / (main[0] + pers[0]), small[0], (small[1] / small[0]) if small[0] else 0.0, 1e3 * r["avg_launch_ms"]))
     fp.write("## rocprofv3 --kernel-trace --stats (bench.py --steps 1 --warmup 1: two passes over the 1600-tile grid)\n\n")
     fp.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
     for r in rows[:16]:
