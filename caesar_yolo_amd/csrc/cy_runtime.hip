@@ -96,7 +96,7 @@ void free_all(cy_ctx* c) {
     if (c->s_fwd2) { hipStreamDestroy(c->s_fwd2); c->s_fwd2 = nullptr; }
     if (c->ws3) hipFree(c->ws3);
     c->ws3 = nullptr; c->ws3_bytes = 0;
-    if (c->s_small) { hipStreamDestroy(c->s_small); c->s_small = nullptr; }
+    c->s_small = nullptr;                                   // (an alias of s_fwd2)
     for (auto& e : c->ev_split) if (e) { hipEventDestroy(e); e = nullptr; }
     for (auto& b : c->sb) {
         void* ptrs[] = {b.netin, b.pred, b.cand, b.cand_anchor, b.cand_count, b.keys, b.det, b.det_anchor, b.det_count,
@@ -524,25 +524,35 @@ int cy_forward(cy_ctx* c, const void* d_netin, int B, int H, int W, float* d_pre
 // kernels fill those tails.  Measured on MI355X (tools/concurrent_forward.py, forward only): -6.8 % at 208 tiles, -3.7 % at
 // 224, -1.3 % at 254.  Used for 64..239 tiles (the per-rank shares at N >= 2); a full batch stays on one stream, so that the
 // per-launch event timing of bench.py at N = 1 means exclusive use of the GPU.  CY_DUAL_FORWARD: 0 off, 2 from 2 tiles on.
+// ONE extra forward stream serves both the second half of a split batch and the small-batch lane.  With a stream of its own per
+// role a context had five streams (caller's, preprocessing, post-processing, split, small lane) and the HIP runtime maps streams
+// onto FOUR hardware queues: whichever two shared a queue serialised -- measured as a per-rank pass of 41.6 instead of 24.6 ms when
+// one process used both roles (a rank of the N = 2 / 4 partitions: full batches of 64..239 tiles AND ragged classes; order of
+// stream creation decided which pair collided).  A small batch now queues behind the second half of a split batch when both are
+// in flight; at N = 1 (no split batches) and N = 8 (a rank has either kind) nothing changes.
+static int ensure_side_forward_stream(cy_ctx* c) {
+    if (c->s_fwd2) return CY_OK;
+    HIPCHK(c, hipStreamCreateWithFlags(&c->s_fwd2, hipStreamNonBlocking));
+    return CY_OK;
+}
 static int ensure_second_workspace(cy_ctx* c) {
     if (c->ws2) return CY_OK;
     c->ws2_bytes = c->ws_bytes / 2 + (1u << 20);            // the second half is never the larger one
     HIPCHK(c, hipMalloc(&c->ws2, c->ws2_bytes));
-    HIPCHK(c, hipStreamCreateWithFlags(&c->s_fwd2, hipStreamNonBlocking));
+    int rc = ensure_side_forward_stream(c);
+    if (rc) return rc;
     for (auto& ev : c->ev_split) HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     return CY_OK;
 }
-// The small-batch lane (cy_detect_tiles): batches of fewer than 64 tiles run their forward on a stream of the LOWEST priority
-// with a workspace of their own, so that their ~105 launches of a few workgroups each take what the full batch beside them
-// leaves free instead of competing with it.
+// The small-batch lane (cy_detect_tiles): small batches run their forward on the side forward stream with a workspace of their
+// own, so that their ~105 launches of a few workgroups each take what the full batch beside them leaves free.
 static int ensure_small_lane(cy_ctx* c) {
     if (c->ws3) return CY_OK;
     c->ws3_bytes = c->ws_bytes / 3 + (1u << 20);            // a small batch holds at most max_batch / 3 tiles
     HIPCHK(c, hipMalloc(&c->ws3, c->ws3_bytes));
-    int prio_lo = 0, prio_hi = 0;
-    hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    static const int low = env_knob("CY_SMALL_PRIO", 1);
-    HIPCHK(c, hipStreamCreateWithPriority(&c->s_small, hipStreamNonBlocking, low ? prio_lo : 0));
+    int rc = ensure_side_forward_stream(c);
+    if (rc) return rc;
+    c->s_small = c->s_fwd2;                                 // (shared: see ensure_side_forward_stream)
     return CY_OK;
 }
 static int dual_mode() { const char* e = getenv("CY_DUAL_FORWARD"); return e ? atoi(e) : 1; }

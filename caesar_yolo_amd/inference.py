@@ -43,7 +43,7 @@ def shard(items, rank, world):
 # in two 30.5 ms, in three 36.6 ms; full rate 7285 tiles/s -> 12-25 tile-equivalents per batch; small batches of
 # ragged tiles run well below the full rate).
 BATCH_OVERHEAD_TILES = 26.0      # refit after the fused stem kernel: world 8 and 4 emulation (tools/emulate_ranks.py), 0.116 ms per tile
-SMALL_BATCH_EXTRA_TILES = 5.0    # (batch-invariant selection: small batches run kernels tuned for 256 tiles)
+SMALL_BATCH_EXTRA_TILES = 7.5    # (refit in round 3 on the N = 8 emulation: the rank that inherits the four small batches ran 1.0 ms behind the others at 5.0)
 
 
 def _rank_cost(segments, cost, batch):

@@ -1,5 +1,5 @@
 """Time every rank's LOCAL share of the S16k grid at a given world size, one after the other on one GPU (developer tool):
-the N-GPU step time is max over ranks of this + gather + cross-tile merge.  python tools/emulate_ranks.py [world] [batch]"""
+the N-GPU step time is max over ranks of this + gather + cross-tile merge.  python tools/emulate_ranks.py [world] [batch] [size] [rank,rank,...]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -17,8 +17,9 @@ det = m.engine(0)
 mos = det.mosaic_to_device(synth.make_mosaic(size, seed=20260104))
 grid = utils.generate_tiles(0, size - 1, 0, size - 1, 512, 512, 0.8, 0.8)
 cfg = PP.DataPreprocessor([PP.ZScaleTransformer([0.25] * 3), PP.MinMaxNormalizer(0, 255)]).program()
+only = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else list(range(world))      # ranks to time (default: all)
 worst = 0.0
-for r in range(world):
+for r in only:
     eng = TileEngine(det, mos, grid, cfg, 512, 0.7, 0.5, 0.3, 0.8, r, world, batch)
     for _ in range(2):
         eng.run_local()
