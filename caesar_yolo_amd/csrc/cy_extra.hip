@@ -15,13 +15,20 @@ template <> struct Vec8<f16> { typedef f16 type __attribute__((ext_vector_type(8
 template <> struct Vec8<float> { typedef float type __attribute__((ext_vector_type(8))); };
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+// fp16x3 context (SPLIT): a value is the sum of two fp16 halves, the low one `lo` elements behind the high one (cy_kernels.h)
+template <bool SPLIT, typename T> __device__ __forceinline__ float ld1(const T* p, int lo) {
+    if constexpr (SPLIT) return (float)p[0] + (float)p[lo]; else return (float)p[0];
+}
+template <bool SPLIT, typename T> __device__ __forceinline__ void st1(T* p, int lo, float v) {
+    if constexpr (SPLIT) { const T h = (T)v; p[0] = h; p[lo] = (T)(v - (float)h); } else p[0] = (T)v;
+}
 
 // ------------------------------------------------------------------------------------------------ depth-wise 3x3, stride 1
 // out[b,y,x,c] = act( sum_{kh,kw} in[b,y+kh-1,x+kw-1,map(c)] * w[kh*3+kw][c] + bias[c] ) (+ res[b,y,x,c])
 // One thread = one pixel x 8 channels (16-byte loads in fp16).  map(c) is the identity, or - for the positional-encoding
 // conv of the attention block - the channel of `v` inside the per-head [q|k|v] blocks of the qkv tensor:
 // map(c) = (c / blk) * gstride + goff + c % blk  (blk is a multiple of 8).
-template <typename T>
+template <typename T, bool SPLIT = false>
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(const DwArgs a) {
     typedef typename Vec8<T>::type v8;
     const int cg = a.C / 8;
@@ -44,11 +51,36 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const DwArgs a) {
                 const T* ip = reinterpret_cast<const T*>(a.in) + (((long)b * a.H + yy) * a.W + xx) * a.in_ct + a.in_coff + cin;
                 const v8 v = *reinterpret_cast<const v8*>(ip);
                 const float* w = a.w + (kh * 3 + kw) * a.C + c;
+                if constexpr (SPLIT) {
+                    const v8 vl = *reinterpret_cast<const v8*>(ip + a.in_lo);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] = fmaf((float)v[j], w[j], acc[j]);
+                    for (int j = 0; j < 8; ++j) acc[j] = fmaf((float)v[j] + (float)vl[j], w[j], acc[j]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = fmaf((float)v[j], w[j], acc[j]);
+                }
             }
         v8 o;
         const long opix = ((long)b * a.H + y) * a.W + x;
+        if constexpr (SPLIT) {
+            float rr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (a.res) {
+                const T* rp = reinterpret_cast<const T*>(a.res) + opix * a.res_ct + a.res_coff + c;
+                const v8 r = *reinterpret_cast<const v8*>(rp), rl = *reinterpret_cast<const v8*>(rp + a.res_lo);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) rr[j] = (float)r[j] + (float)rl[j];
+            }
+            v8 ol;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = (a.act ? silu_f(acc[j]) : acc[j]) + rr[j];
+                o[j] = (T)v; ol[j] = (T)(v - (float)o[j]);
+            }
+            T* op = reinterpret_cast<T*>(a.out) + opix * a.out_ct + a.out_coff + c;
+            *reinterpret_cast<v8*>(op) = o;
+            *reinterpret_cast<v8*>(op + a.out_lo) = ol;
+            continue;
+        }
         if (a.res) {
             const v8 r = *reinterpret_cast<const v8*>(reinterpret_cast<const T*>(a.res) + opix * a.res_ct + a.res_coff + c);
 #pragma unroll
@@ -66,6 +98,7 @@ hipError_t launch_dwconv(Precision p, const DwArgs& a, hipStream_t s) {
     const long total = (long)a.B * a.H * a.W * (a.C / 8);
     const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     if (p == PREC_F16) hipLaunchKernelGGL(dwconv3x3_kernel<f16>, dim3(grid), dim3(256), 0, s, a);
+    else if (p == PREC_F16X3) hipLaunchKernelGGL((dwconv3x3_kernel<f16, true>), dim3(grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(dwconv3x3_kernel<float>, dim3(grid), dim3(256), 0, s, a);
     return hipGetLastError();
 }
@@ -75,7 +108,7 @@ hipError_t launch_dwconv(Precision p, const DwArgs& a, hipStream_t s) {
 // out[b][n][head*hd + c] = sum_m softmax_m( scale * <q_n, k_m> ) * v[m][c],  scale = kd^-0.5.
 // One wave per query: lanes stride over the keys for the scores (kept in LDS), wave-reduce max and sum, then lane c
 // accumulates channel c over all keys (hd = 64 = one channel per lane).  fp32 arithmetic throughout.
-template <typename T>
+template <typename T, bool SPLIT = false>
 __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     extern __shared__ float sc[];                            // [4 waves][N]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -88,12 +121,12 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     float* s = sc + wave * a.N;
     float q[64];                                             // kd <= 64
     const T* qp = base + (long)n * a.ct;
-    for (int d = 0; d < a.kd; ++d) q[d] = (float)qp[d];
+    for (int d = 0; d < a.kd; ++d) q[d] = ld1<SPLIT>(qp + d, a.lo);
     float mx = -INFINITY;
     for (int m = lane; m < a.N; m += 64) {
         const T* kp = base + (long)m * a.ct + a.kd;
         float t = 0.0f;
-        for (int d = 0; d < a.kd; ++d) t = fmaf(q[d], (float)kp[d], t);
+        for (int d = 0; d < a.kd; ++d) t = fmaf(q[d], ld1<SPLIT>(kp + d, a.lo), t);
         t *= a.scale;
         s[m] = t;
         mx = fmaxf(mx, t);
@@ -108,8 +141,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     for (int c = lane; c < a.hd; c += 64) {
         float acc = 0.0f;
         const T* vp = base + 2 * a.kd + c;
-        for (int m = 0; m < a.N; ++m) acc = fmaf(s[m], (float)vp[(long)m * a.ct], acc);
-        reinterpret_cast<T*>(a.out)[((long)b * a.N + n) * a.out_ct + a.out_coff + head * a.hd + c] = (T)(acc * inv);
+        for (int m = 0; m < a.N; ++m) acc = fmaf(s[m], ld1<SPLIT>(vp + (long)m * a.ct, a.lo), acc);
+        st1<SPLIT>(reinterpret_cast<T*>(a.out) + ((long)b * a.N + n) * a.out_ct + a.out_coff + head * a.hd + c, a.out_lo, acc * inv);
     }
 }
 
@@ -117,7 +150,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
 // query (or a few, for maps with more than 256 pixels) and walks the keys with an online softmax, reading K[m] and V[m] as
 // wave-wide broadcasts.  256 tokens: 96 KiB of LDS, 0.15 ms for all heads of a 64-image batch (the per-query kernel above
 // re-reads K and V from L2 for every query and took 1.4 ms); used whenever K and V fit in 160 KiB.
-template <typename T, int KD, int HD>
+template <typename T, int KD, int HD, bool SPLIT = false>
 __global__ __launch_bounds__(256) void attention_lds_kernel(const AttnArgs a) {
     extern __shared__ float kv[];                            // K [N][KD] | V [N][HD]
     float* Ks = kv;
@@ -129,20 +162,20 @@ __global__ __launch_bounds__(256) void attention_lds_kernel(const AttnArgs a) {
         const int m = i / (KD / 8), c8 = (i % (KD / 8)) * 8;
         const T* p = base + (long)m * a.ct + KD + c8;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) Ks[m * KD + c8 + j] = (float)p[j];
+        for (int j = 0; j < 8; ++j) Ks[m * KD + c8 + j] = ld1<SPLIT>(p + j, a.lo);
     }
     for (int i = threadIdx.x; i < a.N * (HD / 8); i += 256) {
         const int m = i / (HD / 8), c8 = (i % (HD / 8)) * 8;
         const T* p = base + (long)m * a.ct + 2 * KD + c8;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) Vs[m * HD + c8 + j] = (float)p[j];
+        for (int j = 0; j < 8; ++j) Vs[m * HD + c8 + j] = ld1<SPLIT>(p + j, a.lo);
     }
     __syncthreads();
     for (int n = threadIdx.x; n < a.N; n += 256) {
         float q[KD], o[HD];
         const T* qp = base + (long)n * a.ct;
 #pragma unroll
-        for (int d = 0; d < KD; ++d) q[d] = (float)qp[d] * a.scale;
+        for (int d = 0; d < KD; ++d) q[d] = ld1<SPLIT>(qp + d, a.lo) * a.scale;
 #pragma unroll
         for (int c = 0; c < HD; ++c) o[c] = 0.0f;
         float mx = -INFINITY, sum = 0.0f;
@@ -167,7 +200,7 @@ __global__ __launch_bounds__(256) void attention_lds_kernel(const AttnArgs a) {
         const float inv = 1.0f / sum;
         T* op = reinterpret_cast<T*>(a.out) + ((long)b * a.N + n) * a.out_ct + a.out_coff + head * HD;
 #pragma unroll
-        for (int c = 0; c < HD; ++c) op[c] = (T)(o[c] * inv);
+        for (int c = 0; c < HD; ++c) st1<SPLIT>(op + c, a.out_lo, o[c] * inv);
     }
 }
 
@@ -178,10 +211,12 @@ hipError_t launch_attention(Precision p, const AttnArgs& a, hipStream_t s) {
         if (!fast_attr) {
             hipFuncSetAttribute(reinterpret_cast<const void*>(attention_lds_kernel<f16, 32, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             hipFuncSetAttribute(reinterpret_cast<const void*>(attention_lds_kernel<float, 32, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(attention_lds_kernel<f16, 32, 64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             fast_attr = true;
         }
         const int grid = a.B * a.heads;
         if (p == PREC_F16) hipLaunchKernelGGL((attention_lds_kernel<f16, 32, 64>), dim3(grid), dim3(256), fast_lds, s, a);
+        else if (p == PREC_F16X3) hipLaunchKernelGGL((attention_lds_kernel<f16, 32, 64, true>), dim3(grid), dim3(256), fast_lds, s, a);
         else hipLaunchKernelGGL((attention_lds_kernel<float, 32, 64>), dim3(grid), dim3(256), fast_lds, s, a);
         return hipGetLastError();
     }
@@ -192,10 +227,12 @@ hipError_t launch_attention(Precision p, const AttnArgs& a, hipStream_t s) {
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<f16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     const int grid = (int)((nq + 3) / 4);
     if (p == PREC_F16) hipLaunchKernelGGL(attention_kernel<f16>, dim3(grid), dim3(256), lds, s, a);
+    else if (p == PREC_F16X3) hipLaunchKernelGGL((attention_kernel<f16, true>), dim3(grid), dim3(256), lds, s, a);
     else hipLaunchKernelGGL(attention_kernel<float>, dim3(grid), dim3(256), lds, s, a);
     return hipGetLastError();
 }

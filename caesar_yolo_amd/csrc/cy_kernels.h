@@ -91,9 +91,11 @@ struct DwArgs {     // depth-wise 3x3 stride 1 over NHWC channel slices; w: [9][
     const void* in; int in_ct, in_coff; void* out; int out_ct, out_coff; const void* res; int res_ct, res_coff;
     const float* w; const float* bias; int B, H, W, C, act;
     int blk, gstride, goff;                            // input channel of output channel c: (c/blk)*gstride + goff + c%blk (blk = 0: c)
+    int in_lo, out_lo, res_lo;                         // fp16x3 context: offsets of the low halves (see ConvArgs)
 };
 struct AttnArgs {   // softmax(q^T k * scale) applied to v, per head; qkv channels per head: [q kd | k kd | v hd]
     const void* qkv; int ct, coff; void* out; int out_ct, out_coff; int B, N, heads, kd, hd; float scale;
+    int lo, out_lo;                                    // fp16x3 context: offsets of the low halves of qkv / out
 };
 hipError_t launch_dwconv(Precision p, const DwArgs& a, hipStream_t s);
 hipError_t launch_attention(Precision p, const AttnArgs& a, hipStream_t s);

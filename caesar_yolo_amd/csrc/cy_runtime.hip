@@ -341,9 +341,6 @@ int upload_weights(cy_ctx* c, const void* buf, size_t nbytes) {
         const std::string bad = validate_plan(plan);
         if (!bad.empty()) { free_all(c); return fail(c, CY_ERR_IO, "malformed CYW2 plan: " + bad); }
     }
-    if (c->prec == PREC_F16X3)
-        for (const Op& o : plan.ops)
-            if (o.kind == OPK_DWCONV || o.kind == OPK_ATTN) { free_all(c); return fail(c, CY_ERR_UNSUPPORTED, "the fp16x3 context runs YOLOv8 plans only (no depth-wise / attention kernels yet): use fp32 or fp16"); }
     if (c->prec == PREC_F16) {
         std::vector<char> wf(BNECK_WFRAG_BYTES);
         for (size_t i = 0; i + 1 < plan.ops.size(); ++i) {
@@ -703,8 +700,9 @@ static int forward_on(cy_ctx* c, const void* d_netin, int B, int H, int W, float
             const ConvDesc& d = p.convs[o.conv];
             const Tensor& ti = p.tensors[o.in0]; const Tensor& to = p.tensors[o.out];
             DwArgs a{};
-            a.in = tp(o.in0); a.in_ct = ti.C; a.in_coff = o.in0_coff; a.out = tp(o.out); a.out_ct = to.C; a.out_coff = o.out_coff;
-            if (o.res >= 0) { a.res = tp(o.res); a.res_ct = p.tensors[o.res].C; a.res_coff = o.res_coff; }
+            a.in = tp(o.in0); a.in_ct = cm * ti.C; a.in_coff = o.in0_coff; a.out = tp(o.out); a.out_ct = cm * to.C; a.out_coff = o.out_coff;
+            a.in_lo = ti.C; a.out_lo = to.C;
+            if (o.res >= 0) { a.res = tp(o.res); a.res_ct = cm * p.tensors[o.res].C; a.res_coff = o.res_coff; a.res_lo = p.tensors[o.res].C; }
             a.w = c->dconv[o.conv].dw_w; a.bias = c->dconv[o.conv].bias;
             a.B = Bn; a.H = H >> ti.level; a.W = W >> ti.level; a.C = d.cout; a.act = d.act;
             a.blk = o.p0; a.gstride = o.p1; a.goff = o.p2;
@@ -714,7 +712,8 @@ static int forward_on(cy_ctx* c, const void* d_netin, int B, int H, int W, float
         } else if (o.kind == OPK_ATTN) {
             const Tensor& ti = p.tensors[o.in0]; const Tensor& to = p.tensors[o.out];
             AttnArgs a{};
-            a.qkv = tp(o.in0); a.ct = ti.C; a.coff = o.in0_coff; a.out = tp(o.out); a.out_ct = to.C; a.out_coff = o.out_coff;
+            a.qkv = tp(o.in0); a.ct = cm * ti.C; a.coff = o.in0_coff; a.out = tp(o.out); a.out_ct = cm * to.C; a.out_coff = o.out_coff;
+            a.lo = ti.C; a.out_lo = to.C;
             a.B = Bn; a.N = (H >> ti.level) * (W >> ti.level); a.heads = o.p0; a.kd = o.p1; a.hd = o.p2;
             a.scale = 1.0f / sqrtf((float)a.kd);
             if (a.heads < 1 || ti.level != to.level) return fail(c, CY_ERR_STATE, "malformed attention op");

@@ -15,8 +15,8 @@ TAPS = ["model.1", "model.2.cv2", "model.9.cv2", "model.10.cv2", "model.13.cv2",
         "model.23.cv3.0.0.0", "model.23.cv3.1.1.1"]
 
 
-@pytest.mark.parametrize("scale,prec,tol_raw,tol_tap", [("n", "fp32", 2e-4, 1e-4), ("n", "fp16", 6e-2, 3e-2),
-                                                        ("l", "fp32", 2e-4, 1e-4), ("l", "fp16", 6e-2, 3e-2)])
+@pytest.mark.parametrize("scale,prec,tol_raw,tol_tap", [("n", "fp32", 2e-4, 1e-4), ("n", "fp16", 6e-2, 3e-2), ("n", "fp16x3", 2e-4, 1e-4),
+                                                        ("l", "fp32", 2e-4, 1e-4), ("l", "fp16", 6e-2, 3e-2), ("l", "fp16x3", 2e-4, 1e-4)])
 def test_yolo11_forward_matches_oracle(tmp_path, scale, prec, tol_raw, tol_tap):
     from caesar_yolo_amd import weights as W
     from caesar_yolo_amd.model import HipDetector
