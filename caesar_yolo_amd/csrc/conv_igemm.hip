@@ -1742,7 +1742,8 @@ __device__ __forceinline__ int strip_div(int e, unsigned long long m) { return (
 
 template <bool SPLIT, bool RES, int STRIP = 0>
 __global__ __launch_bounds__(512) void conv3x3_widep_kernel(const ConvArgs a, const int total, const StripGeo sg) {
-    static_assert(!SPLIT, "fp16x3 form: not written yet (conv3x3_wide_kernel carries it)");
+    // SPLIT (fp16x3 context): three passes over the halo slabs [x_lo | x_hi | x_hi] against the packed weight slabs [w_hi | w_lo | w_hi]
+    // (see conv3x3_wide_kernel); epilogue acc * oscale + bias, SiLU, + residual (hi + lo), stored as high / low halves
     constexpr int NST = 9, TH = 16, TW = 32, NW = 8, BN = 128, PWID = TW + 2;
     // Only waves 0-3 (one per SIMD) issue LDS-DMA.  A wave whose request does not fit the memory pipeline waits at the issue, and
     // cannot issue MFMAs meanwhile; with every wave issuing its share at the same point of a stage both waves of a SIMD wait
@@ -1762,10 +1763,12 @@ __global__ __launch_bounds__(512) void conv3x3_widep_kernel(const ConvArgs a, co
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     const int cpad = pad128(a.Cout);
     const int ntn = (pad64(a.Cout) + BN - 1) / BN;
-    const int pairs = a.Cin / 64;
+    const int ppairs = a.Cin / 64;                          // slab pairs of one pass over the input channels
+    const int pairs = SPLIT ? 3 * ppairs : ppairs;
     const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in0), 0, a.in0_bytes, 0x00020000);
     const auto rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wgt32), 0, a.wgt32_bytes, 0x00020000);
     const auto rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, (unsigned)pad64(a.Cout) * 4u, 0x00020000);
+    const auto rss = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(SPLIT ? a.oscale : a.bias), 0, (unsigned)pad64(a.Cout) * 4u, 0x00020000);
     const unsigned out_bytes = (unsigned)((long)a.B * H * W * a.out_ct * 2);
     const auto rso = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, out_bytes, 0x00020000);
     const auto rsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(RES ? a.res : a.in0), 0,
@@ -1794,6 +1797,12 @@ __global__ __launch_bounds__(512) void conv3x3_widep_kernel(const ConvArgs a, co
         int l4 = lane >> 2;
         asm volatile("" : "+v"(l4));                         // (keeps the optimiser from hoisting the ten offsets out of the stage loop)
         const unsigned lq = (unsigned)(lane & 3);
+        unsigned slab_so = (unsigned)slab * 64u;             // fp16x3: virtual slab -> physical slab (+ the low halves in the first pass)
+        if constexpr (SPLIT) {
+            int lo;
+            slab_so = (unsigned)x3_chunk(slab, 2 * ppairs, lo) * 64u;
+            if (lo) slab_so += (unsigned)a.in0_lo * 2u;
+        }
         if constexpr (STRIP != 0) {
             // staged entry le of the strip = entry gx0 - RS - 1 + le of the flattened batch -> (image, row, column) or a zero
             const int hl = 514 + 2 * sg.RS;
@@ -1808,7 +1817,7 @@ __global__ __launch_bounds__(512) void conv3x3_widep_kernel(const ConvArgs a, co
                 const unsigned q = lq ^ (unsigned)(((le >> 2) & 1) << 1);
                 const bool ok = in && y < H && x < W;
                 const unsigned off = ok ? (unsigned)(((bb * H + y) * W + x) * a.in0_ct + a.in0_coff + (int)q * 8) * 2u : CY_OOB;
-                dma_piece(rs0, (lds_ptr_t*)(Pbuf + buf * P_BYTES + (j * NDW + wave) * 1024), off, (unsigned)slab * 64u);
+                dma_piece(rs0, (lds_ptr_t*)(Pbuf + buf * P_BYTES + (j * NDW + wave) * 1024), off, slab_so);
             }
             return;
         }
@@ -1820,7 +1829,7 @@ __global__ __launch_bounds__(512) void conv3x3_widep_kernel(const ConvArgs a, co
             const unsigned q = lq ^ (unsigned)(((r >> 2) & 1) << 1);
             const bool ok = r < PR && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
             const unsigned off = ok ? (unsigned)(((gb * H + y) * W + x) * a.in0_ct + a.in0_coff + (int)q * 8) * 2u : CY_OOB;
-            dma_piece(rs0, (lds_ptr_t*)(Pbuf + buf * P_BYTES + (j * NDW + wave) * 1024), off, (unsigned)slab * 64u);
+            dma_piece(rs0, (lds_ptr_t*)(Pbuf + buf * P_BYTES + (j * NDW + wave) * 1024), off, slab_so);
         }
     };
     // (lane-dependent LDS / weight addresses are recomputed at the top of every patch instead of living through the epilogue,
@@ -1838,9 +1847,12 @@ __global__ __launch_bounds__(512) void conv3x3_widep_kernel(const ConvArgs a, co
                           (unsigned)((sl * 9 + tap) * cpad * 64 + n0 * 64 + h * 1024));
         }
     };
-    float* const bias_lds = reinterpret_cast<float*>(smem + 2 * P_BYTES + RING * W_BYTES);       // two slots of 1 KiB, alternating per patch
+    // two slots of 2 KiB, alternating per patch: [bias 512 B | 512 B written with zeros | oscale 512 B (fp16x3) | zeros]
+    float* const bias_lds = reinterpret_cast<float*>(smem + 2 * P_BYTES + RING * W_BYTES);
     auto dma_bias = [&](int slot, int n0) {
-        if (wave == 0) dma_piece(rsb, (lds_ptr_t*)(bias_lds + slot * 256), lane * 16 < BN * 4 ? (unsigned)(n0 * 4 + lane * 16) : CY_OOB, 0);
+        if (wave != 0) return;
+        dma_piece(rsb, (lds_ptr_t*)(bias_lds + slot * 512), lane * 16 < BN * 4 ? (unsigned)(n0 * 4 + lane * 16) : CY_OOB, 0);
+        if constexpr (SPLIT) dma_piece(rss, (lds_ptr_t*)(bias_lds + slot * 512 + 256), lane * 16 < BN * 4 ? (unsigned)(n0 * 4 + lane * 16) : CY_OOB, 0);
     };
 
     f32x4 acc[4][MIW];
@@ -1975,12 +1987,14 @@ __global__ __launch_bounds__(512) void conv3x3_widep_kernel(const ConvArgs a, co
         }
         if (stamps) t_l1 = stamp_real();
         // ---- epilogue of this patch.  Stage 0 of the next patch needs nothing but what the last barrier has already published.
-        const float* bl = bias_lds + (n & 1) * 256 + wn * 64 + fq * 16;
+        const float* bl = bias_lds + (n & 1) * 512 + wn * 64 + fq * 16;
         float bv[16];
+        if constexpr (!SPLIT) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(bl + j * 4);
-            bv[j * 4] = t[0]; bv[j * 4 + 1] = t[1]; bv[j * 4 + 2] = t[2]; bv[j * 4 + 3] = t[3];
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(bl + j * 4);
+                bv[j * 4] = t[0]; bv[j * 4 + 1] = t[1]; bv[j * 4 + 2] = t[2]; bv[j * 4 + 3] = t[3];
+            }
         }
         const int cbase = n0 + wn * 64 + fq * 16;
         const bool chan_ok = cbase + 16 <= a.Cout;
@@ -2013,6 +2027,56 @@ __global__ __launch_bounds__(512) void conv3x3_widep_kernel(const ConvArgs a, co
                 return (y0 + wm * RPW + (mi >> 1) < H) && ((mi & 1) ? okx1 : okx0);
             }
         };
+        if constexpr (SPLIT) {
+            // residual = high + low halves: four 16-byte loads per pixel fragment, requested two fragments ahead of the arithmetic (a ring
+            // of three fragments: 48 registers; the compiler places the waits).  The stores are issued by every lane (out-of-range ones
+            // are dropped by the range check).
+            f16x8 rq[3][4];
+            auto res_load = [&](int mi) {
+                unsigned pix;
+                const bool ok = pixel(mi, pix);
+                const unsigned ro = ok ? (pix * (unsigned)a.res_ct + (unsigned)a.res_coff) * 2u + cb2 : CY_OOB;
+                rq[mi % 3][0] = __builtin_bit_cast(f16x8, load_b128(rsr, ro, 0));
+                rq[mi % 3][1] = __builtin_bit_cast(f16x8, load_b128(rsr, ro, 16));
+                rq[mi % 3][2] = __builtin_bit_cast(f16x8, load_b128(rsr, ro, a.res_lo * 2));
+                rq[mi % 3][3] = __builtin_bit_cast(f16x8, load_b128(rsr, ro, a.res_lo * 2 + 16));
+            };
+            if (RES) { res_load(0); res_load(1); }
+            if (stamps) t_rw = stamp_real();
+#pragma unroll
+            for (int mi = 0; mi < MIW; ++mi) {
+                if (RES && mi + 2 < MIW) res_load(mi + 2);
+                float bg[16], sc[16];          // (re-read from the LDS slot per fragment: 32 registers that need not live through the epilogue)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(bl + j * 4), u = *reinterpret_cast<const f32x4*>(bl + 256 + j * 4);
+                    bg[j * 4] = t[0]; bg[j * 4 + 1] = t[1]; bg[j * 4 + 2] = t[2]; bg[j * 4 + 3] = t[3];
+                    sc[j * 4] = u[0]; sc[j * 4 + 1] = u[1]; sc[j * 4 + 2] = u[2]; sc[j * 4 + 3] = u[3];
+                }
+                float vv[16];
+                scale_bias_act16(acc[0][mi], acc[1][mi], acc[2][mi], acc[3][mi], bg, sc, a.act != 0, vv);
+                if (RES) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        vv[j] += (float)rq[mi % 3][0][j] + (float)rq[mi % 3][2][j];
+                        vv[8 + j] += (float)rq[mi % 3][1][j] + (float)rq[mi % 3][3][j];
+                    }
+                }
+                f16x8 h0, h1, l0, l1;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    h0[j] = (f16)vv[j]; h1[j] = (f16)vv[8 + j];
+                    l0[j] = (f16)(vv[j] - (float)h0[j]); l1[j] = (f16)(vv[8 + j] - (float)h1[j]);
+                }
+                unsigned pix;
+                const bool ok = pixel(mi, pix);
+                const unsigned so = ok ? (pix * (unsigned)a.out_ct + (unsigned)a.out_coff) * 2u + cb2 : CY_OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h0), rso, so, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h1), rso, so, 16, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, l0), rso, so, a.out_lo * 2, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, l1), rso, so, a.out_lo * 2 + 16, 0);
+            }
+        } else {
         f16x8 rv[MIW][2];
         if (RES) {
 #pragma unroll
@@ -2043,6 +2107,7 @@ __global__ __launch_bounds__(512) void conv3x3_widep_kernel(const ConvArgs a, co
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rso, so, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), rso, so, 16, 0);
         }
+        }
         if (stamps) t_ep = stamp_real();
         if (stamps && !next && tid == 0) g_wg_stamps[(size_t)(blockIdx.x % WG_STAMP_SLOTS) * 4 + 3] = t_ep - t_begin;    // [3] the workgroup's whole life
         if (!next) break;
@@ -2050,26 +2115,26 @@ __global__ __launch_bounds__(512) void conv3x3_widep_kernel(const ConvArgs a, co
     }
 }
 
-template <int STRIP>
+template <int STRIP, bool SPLIT = false>
 static hipError_t launch_widep_t(const ConvArgs& a, hipStream_t s, int total, const StripGeo& sg) {
     constexpr int PR = 18 * 34, NPC = (PR + 15) / 16, PROUNDS = STRIP ? STRIP : (NPC + 3) / 4;
-    const size_t lds = 2 * PROUNDS * 4 * 1024 + 3 * 2 * 128 * 64 + 2048;        // halo x2, weight ring, bias x2
+    const size_t lds = 2 * PROUNDS * 4 * 1024 + 3 * 2 * 128 * 64 + 4096;        // halo x2, weight ring, bias (+ oscale) x2
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_widep_kernel<false, false, STRIP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_widep_kernel<false, true, STRIP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_widep_kernel<SPLIT, false, STRIP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_widep_kernel<SPLIT, true, STRIP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     static const int ncu = [] { int dev = 0, n = 256; hipGetDevice(&dev); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
     const int grid = total < ncu ? total : ncu;
-    if (a.res) hipLaunchKernelGGL((conv3x3_widep_kernel<false, true, STRIP>), dim3(grid), dim3(512), lds, s, a, total, sg);
-    else hipLaunchKernelGGL((conv3x3_widep_kernel<false, false, STRIP>), dim3(grid), dim3(512), lds, s, a, total, sg);
+    if (a.res) hipLaunchKernelGGL((conv3x3_widep_kernel<SPLIT, true, STRIP>), dim3(grid), dim3(512), lds, s, a, total, sg);
+    else hipLaunchKernelGGL((conv3x3_widep_kernel<SPLIT, false, STRIP>), dim3(grid), dim3(512), lds, s, a, total, sg);
     return hipGetLastError();
 }
 
 static hipError_t launch_widep(const ConvArgs& a, hipStream_t s) {
     const int total = a.B * ((a.Wi + 31) / 32) * ((a.Hi + 15) / 16) * ((pad64(a.Cout) + 127) / 128);
-    return launch_widep_t<0>(a, s, total, StripGeo{});
+    return a.split ? launch_widep_t<0, true>(a, s, total, StripGeo{}) : launch_widep_t<0>(a, s, total, StripGeo{});
 }
 
 // idle share of the MFMA lanes of the 2-D patch form (16 x 32-pixel patches) and of the strip form on an H x W map
@@ -2082,6 +2147,7 @@ static hipError_t launch_strip(const ConvArgs& a, hipStream_t s) {
     sg.RS = a.Wi + 1; sg.IS = (a.Hi + 1) * sg.RS; sg.NE = a.B * sg.IS;
     sg.mRS = ((1ull << 40) + sg.RS - 1) / sg.RS; sg.mIS = ((1ull << 40) + sg.IS - 1) / sg.IS;
     const int total = ((sg.NE + 511) / 512) * ((pad64(a.Cout) + 127) / 128);
+    if (a.split) return a.Wi <= 62 ? launch_widep_t<10, true>(a, s, total, sg) : launch_widep_t<12, true>(a, s, total, sg);
     return a.Wi <= 62 ? launch_widep_t<10>(a, s, total, sg) : launch_widep_t<12>(a, s, total, sg);
 }
 
@@ -2439,6 +2505,8 @@ static int conv_variant_x3(const ConvArgs& a) {
         const int wpad = (a.Wi + 31) / 32 * 32;
         const bool fits = (wpad - a.Wi) * 8 <= a.Wi;
         if (narrow && a.Wi % 32 == 0) return CONV_WIDE_64;
+        // strip form where 16 x 32 patches would idle > 4 % more lanes (geometry only: no batch threshold in this context)
+        if (!narrow && env_knob("CY_STRIP", 1) && strip_fits(a) && strip_cover(a.Hi, a.Wi) + 0.04 < wide2d_cover(a.Hi, a.Wi)) return CONV_STRIP_128;
         if (!narrow && fits) return CONV_WIDE_128;
         if (!narrow && a.Wi <= 16 && a.Wi >= 14) return CONV_WIDE_DUAL;
     }
@@ -2511,7 +2579,10 @@ hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s) {
     if (p == PREC_F16X3) {
         if (!a.split || !a.oscale) return hipErrorInvalidValue;
         switch (conv_variant_x3(a)) {
-            case CONV_WIDE_128: return launch_wide<2, false, 2, true>(a, s);
+            case CONV_WIDE_128:      // persistent form (bit-identical) with CY_X3_PERSIST=1: measured before it became a default
+                if (env_knob("CY_X3_PERSIST", 0) && a.Cout % 16 == 0) return launch_widep(a, s);
+                return launch_wide<2, false, 2, true>(a, s);
+            case CONV_STRIP_128: return launch_strip(a, s);
             case CONV_WIDE_64: return launch_wide<1, false, 2, true>(a, s);
             case CONV_WIDE_DUAL: return launch_wide<2, true, 2, true>(a, s);
             case CONV_DIRECT_256: return a.k == 3 ? launch_direct<4, 2, 3, true, true>(a, s) : launch_direct<4, 2, 3, false, true>(a, s);

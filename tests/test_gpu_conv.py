@@ -268,3 +268,36 @@ def test_strip_form_of_the_wide_kernel(case, monkeypatch):
     assert err <= 4e-3 * scale, "max abs err %.3e (scale %.2f)" % (err, scale)
     for _ in range(4):
         assert torch.equal(out, det.conv_bn_silu(xd, w.numpy(), b.numpy(), 3, 1, True, rd))
+
+
+@pytest.mark.parametrize("case", [(5, 80, 80, 128, 128, True), (7, 40, 40, 256, 256, False), (9, 20, 20, 512, 256, True), (3, 52, 64, 128, 128, True),
+                                  (2, 33, 47, 64, 192, True), (2, 100, 126, 64, 128, False), (40, 64, 64, 128, 128, True), (3, 32, 64, 256, 256, False)])
+def test_fp16x3_persistent_and_strip_forms(case, monkeypatch):
+    """fp16x3 context: the strip form of the persistent wide kernel (three-pass K walk over the flattened batch, scaled / split epilogue,
+    residual as high + low halves requested two fragments at a time) and, with CY_X3_PERSIST=1, its 2-D form -- against F.conv2d in
+    float64 (4e-6 of the output scale) and bit-identical to the one-patch fp16x3 wide kernel where that one applies."""
+    B, H, W, Cin, Cout, use_res = case
+    det = detector("fp16x3")
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn((B, Cin, H, W), generator=g)
+    w = torch.randn((Cout, Cin, 3, 3), generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn((Cout,), generator=g) * 0.1
+    y = F.silu(F.conv2d(x.double(), w.double(), b.double(), padding=1))
+    res = torch.randn(y.shape, generator=g) if use_res else None
+    if use_res:
+        y = y + res.double()
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    rd = res.permute(0, 2, 3, 1).contiguous().cuda() if use_res else None
+    outs = {}
+    for strip, pers in (("0", "0"), ("1", "1")):
+        monkeypatch.setenv("CY_STRIP", strip)
+        monkeypatch.setenv("CY_X3_PERSIST", pers)
+        out = det.conv_bn_silu(xd, w.numpy(), b.numpy(), 3, 1, True, rd)
+        torch.cuda.synchronize()
+        outs[strip] = out.clone()
+        got = out.double().cpu().permute(0, 3, 1, 2)
+        scale = max(float(y.abs().max()), 1.0)
+        err = float((got - y).abs().max())
+        assert err <= 4e-6 * scale, "strip %s: max abs err %.3e (scale %.2f)" % (strip, err, scale)
+    if W % 32 == 0 and H % 16 == 0:          # both runs took a form of the wide kernel: same arithmetic in the same order
+        assert torch.equal(outs["0"], outs["1"])
