@@ -3082,14 +3082,18 @@ __global__ __launch_bounds__(512) void stem_down2_kernel(const StemDownArgs a) {
     const auto rsi = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, a.in_bytes, 0x00020000);
     const auto rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wgt32), 0, a.wgt32_bytes, 0x00020000);
 
-    // weight fragments of step (tap, h) of the 3x3 s2 conv: rows wn*64 + ni*16 + fr of chunk h, bytes fq*16..
+    // weight fragments of step (tap, h) of the 3x3 s2 conv: rows w4*32 + ni*16 + fr of chunk h, bytes fq*16..
+    // Round 3: a wave convolves ALL 8 output rows of the patch x 32 channels (was 4 rows x 64 channels).  The weight fragments come
+    // straight from L2, per wave and per patch: 4 fragments x 18 steps = 72 KB per wave, 288 KB per patch -- at the 16-17 B per cycle a
+    // CU's fetch path sustains (section 4 of DESIGN.md) that alone was ~9 us per patch, the whole phase.  Two fragments per step feeding
+    // eight pixel fragments halve it (the pixel fragments are LDS reads); outputs are bit-identical (same K order per output).
     constexpr int RING = 4;
-    f16x8 wa[RING][4];
-    const unsigned wl = (unsigned)((wn * 64 + fr) * 64 + fq * 16);
+    f16x8 wa[RING][2];
+    const unsigned wl = (unsigned)((w4 * 32 + fr) * 64 + fq * 16);
     auto load_wa = [&](f16x8* dst, int step) {
         const int h = step & 1, tap = step >> 1;
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) dst[ni] = __builtin_bit_cast(f16x8, load_b128(rsw, wl + ni * 1024, (h * 9 + tap) * 8192));
+        for (int ni = 0; ni < 2; ++ni) dst[ni] = __builtin_bit_cast(f16x8, load_b128(rsw, wl + ni * 1024, (h * 9 + tap) * 8192));
     };
     const f16* wp = reinterpret_cast<const f16*>(a.wpk2);
     const int t0 = 2 * fq, t1 = 2 * fq + 1;                  // the two taps of this lane's k-chunk; tap 8 rides in the second MFMA (fq = 0)
@@ -3169,48 +3173,59 @@ __global__ __launch_bounds__(512) void stem_down2_kernel(const StemDownArgs a) {
     auto conv_store = [&](int n) {
         int b, oy0, ox0;
         coords(n, b, oy0, ox0);
-        f32x4 acc[4][4];
+        f32x4 acc[2][8];
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
+        for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int m = 0; m < 4; ++m) acc[ni][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int pl = wm * 8 * S2_PW + fr;                   // LDS row of (first output row of this wave, tap (0,0), column fr)
+            for (int m = 0; m < 8; ++m) acc[ni][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        unsigned xrow[8];                                     // lane part of a pixel-fragment address for (row offset & 7) = c
+#pragma unroll
+        for (int c = 0; c < 8; ++c) xrow[c] = (unsigned)(fr * 128 + ((fq ^ ((fr + c) & 7)) << 4));
 #pragma unroll
         for (int step = 0; step < 18; ++step) {
             const int tap = step >> 1, h = step & 1, kh = tap / 3, kw = tap % 3;
             if (step + RING - 1 < 18) load_wa(wa[(step + RING - 1) % RING], step + RING - 1);
             __builtin_amdgcn_sched_barrier(0);
-            f16x8 xb[4];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int cm = (2 * m + kh) * S2_PW + (kw == 1 ? S2_EVEN : (kw == 2 ? 1 : 0));
-                const int p = pl + cm;
-                xb[m] = *reinterpret_cast<const f16x8*>(buf + p * 128 + (((h * 4 + fq) ^ (p & 7)) << 4));
+            for (int mh = 0; mh < 2; ++mh) {                  // two half-steps of four pixel fragments (16 registers)
+                f16x8 xb[4];
+#pragma unroll
+                for (int m4 = 0; m4 < 4; ++m4) {
+                    const int m = mh * 4 + m4;
+                    const int cm = (2 * m + kh) * S2_PW + (kw == 1 ? S2_EVEN : (kw == 2 ? 1 : 0));
+                    // row p = fr + cm, chunk (h*4 + fq) ^ (p & 7): one of eight lane bases (by cm & 7), the second K half = bit 6 flipped
+                    xb[m4] = *reinterpret_cast<const f16x8*>(buf + ((xrow[cm & 7] ^ (unsigned)(h * 64)) + cm * 128));
+                }
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int m4 = 0; m4 < 4; ++m4)
+                        acc[ni][mh * 4 + m4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[step % RING][ni], xb[m4], acc[ni][mh * 4 + m4], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-                    acc[ni][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[step % RING][ni], xb[m], acc[ni][m], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
         }
-        const int cbase = wn * 64 + fq * 16;
-        float bv[16];
+        // packed rows w4*32 + ni*16 + (4 fq + j) hold channels 64 (w4 >> 1) + 16 fq + 4 (2 (w4 & 1) + ni) + j: 8 contiguous channels per lane
+        const int cbase = (w4 >> 1) * 64 + fq * 16 + (w4 & 1) * 8;
+        f32x2 bv[4];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) bv[j] = a.bias1[cbase + j];
+        for (int j = 0; j < 4; ++j) bv[j] = f32x2{a.bias1[cbase + 2 * j], a.bias1[cbase + 2 * j + 1]};
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int oy = oy0 + wm * 4 + m, ox = ox0 + fr;
+        for (int m = 0; m < 8; ++m) {
+            const int oy = oy0 + m, ox = ox0 + fr;
             if (oy >= a.Ho || ox >= a.Wo) continue;
             const long pix = ((long)b * a.Ho + oy) * a.Wo + ox;
-            f16x8 o0, o1;
-            float v16[16];
-            bias_act16(acc[0][m], acc[1][m], acc[2][m], acc[3][m], bv, true, v16);
+            f16x8 o;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { o0[j] = (f16)v16[j]; o1[j] = (f16)v16[8 + j]; }
-            f16* dst = reinterpret_cast<f16*>(a.out) + pix * a.out_ct + a.out_coff + cbase;
-            *reinterpret_cast<f16x8*>(dst) = o0;
-            *reinterpret_cast<f16x8*>(dst + 8) = o1;
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {          // bias + SiLU, two values per instruction (as bias_act16)
+                    f32x2 t = f32x2{acc[ni][m][2 * hh], acc[ni][m][2 * hh + 1]} + bv[ni * 2 + hh];
+                    f32x2 e = t * f32x2{-1.44269504088896341f, -1.44269504088896341f};
+                    e = f32x2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])} + f32x2{1.0f, 1.0f};
+                    t = t * f32x2{__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+                    o[ni * 4 + 2 * hh] = (f16)t[0]; o[ni * 4 + 2 * hh + 1] = (f16)t[1];
+                }
+            *reinterpret_cast<f16x8*>(reinterpret_cast<f16*>(a.out) + pix * a.out_ct + a.out_coff + cbase) = o;
         }
     };
 
