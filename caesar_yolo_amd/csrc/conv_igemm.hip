@@ -3087,6 +3087,11 @@ __global__ __launch_bounds__(512) void stem_down2_kernel(const StemDownArgs a) {
     // straight from L2, per wave and per patch: 4 fragments x 18 steps = 72 KB per wave, 288 KB per patch -- at the 16-17 B per cycle a
     // CU's fetch path sustains (section 4 of DESIGN.md) that alone was ~9 us per patch, the whole phase.  Two fragments per step feeding
     // eight pixel fragments halve it (the pixel fragments are LDS reads); outputs are bit-identical (same K order per output).
+    // Measured: 1.17-1.25 -> 1.09-1.11 ms per 256 tiles, less than the halved fetch promised: the FILL phase (27 eight-byte gathers per
+    // wave and patch + 144 SiLUs per lane) now sets the phase time.  A weight-STATIONARY form was built on that reading and thrown away
+    // again: four-wave workgroups, two per CU, 14 of the 18 K steps of a wave's 32-channel weight slice held in registers for the whole
+    // kernel (112 VGPRs), the stem panel in LDS, gathers three fragments at a time -- bit-identical, 1.20 ms (no fetch of weights per
+    // patch, but no fill / convolve overlap inside a workgroup either, and 32 B of scratch at the 256-register limit).
     constexpr int RING = 4;
     f16x8 wa[RING][2];
     const unsigned wl = (unsigned)((w4 * 32 + fr) * 64 + fq * 16);
