@@ -328,7 +328,8 @@ class YOLO(object):
     deterministic random-init checkpoint used by the tests and the benchmark (no trained weights ship with the
     reference)."""
 
-    def __init__(self, weights, precision="fp16", max_batch=64, max_imgsz=640, device=None):
+    def __init__(self, weights, precision="fp16x3", max_batch=64, max_imgsz=640, device=None):
+        # precision: "fp16x3" (default: the parity context -- the reference runs ultralytics in fp32), "fp32" (exact, slow), "fp16" (3x faster)
         self._wpath = self._resolve(weights)
         self._kw = dict(precision=precision, max_batch=max_batch, max_imgsz=max_imgsz)
         self._det = None
