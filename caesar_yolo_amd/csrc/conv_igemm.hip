@@ -1503,7 +1503,9 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
     // between two barriers 16 + 48 MFMAs of two stages for the first group, 32 + 32 for the second; four-slot weight ring addressed
     // at run time, odd halo slab requested a stage later; one stage loop per group, else the two streams cost 580 B of scratch;
     // bit-identical outputs): 29.10 vs 28.79-28.98 ms forward on the same box, 18-stage layers 5 % slower, 36- and 72-stage layers
-    // unchanged.  So the 1.39 us per stage is not a lock-step effect either.  It is the clock: s_memtime / s_memrealtime over the loop
+    // unchanged.  Nor does it matter WHEN the second wave of a SIMD issues its requests (round 3: waves 4-7 issuing theirs in mid-stage,
+    // behind their first 32 MFMAs, so that the two waves of a SIMD never wait at the memory pipeline together: every wide layer within
+    // +-0.5 % at batch 256).  So the 1.39 us per stage is not a lock-step effect either.  It is the clock: s_memtime / s_memrealtime over the loop
     // give 1.76 GHz for 18-, 36- and 72-stage layers, at which a stage's 2 x 64 MFMAs per SIMD (2048 cycles) would take 1.16 us:
     // the loop runs at 84 % of the matrix-core rate at the clock the chip holds under this load.
     // (tried in round 2, not kept: s_setprio 1 for waves 4-7 before the loop -- static priority for the second-dispatched half,
