@@ -2231,6 +2231,11 @@ __global__ __launch_bounds__(512, (NB * MI <= 4 && RING == 2) ? 2 : 1) void conv
     // of this library tops out at (the wide kernel's requests alone: 15.7 B per cycle).  More requests in flight do not help -- touching
     // the pixel lines 1 / 2 / 4 chunks ahead of the register ring (4-byte LDS-DMA into a dump area) made every 1x1 layer 9-21 % SLOWER --
     // only fewer bytes per MFMA would, and the 256 px x 256 ch tile is the largest the 128 accumulator registers of 8 waves allow.
+    // The lane -> address map of the pixel loads costs a little: the MFMA operand layout puts four DIFFERENT pixels (four 128-byte
+    // lines, 16 bytes of each) into every quad of lanes.  A timing-only build whose quads read 64 contiguous bytes of ONE pixel (same
+    // bytes per instruction, wrong lanes) ran the 1x1 layers 1.5-9.6 % and the strided 3x3 layers 4.6-7.5 % faster (0.39 ms of the
+    // 27.4 ms forward pass at batch 256); getting the data back into operand order is a 4 x 4 lane transpose per register (four
+    // ds_bpermute_b32 per load, or ~20 DPP / permlane-swap moves), which eats most of that -- not built.
     const bool no_dma = CY_STAMPS_ENABLED && (a.dbg & 1), no_rd = CY_STAMPS_ENABLED && (a.dbg & 2), no_mma = CY_STAMPS_ENABLED && (a.dbg & 4),
                no_px = CY_STAMPS_ENABLED && (a.dbg & 8);
     const bool reqw = wave < NDW;
