@@ -7,6 +7,7 @@ TAG=${1:-r02}
 CFG=${2:-s16k}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
+rm -rf $R/gpurun_out/${TAG}_ktrace $R/gpurun_out/${TAG}_pmc_fetch $R/gpurun_out/${TAG}_pmc_write $R/gpurun_out/${TAG}_pmc_sq
 python3 $R/bench.py --config $CFG > $R/gpurun_out/${TAG}_bench.json 2> $R/gpurun_out/${TAG}_bench.err
 echo "bench done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_ktrace -- python3 $R/bench.py --config $CFG --steps 1 --warmup 1 --no-cpu-baseline --no-exclusive > $R/gpurun_out/${TAG}_bench_under_rocprof.json 2>/dev/null
