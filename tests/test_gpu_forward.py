@@ -107,6 +107,24 @@ def test_forward_ragged_letterboxed_shape_fp16(fuse, monkeypatch):
     assert err <= 6e-2 * max(1.0, float(raw.abs().max())), err
 
 
+@pytest.mark.parametrize("imgsz,B", [(128, 3), (1024, 1)])
+def test_forward_at_the_other_published_input_sizes(imgsz, B):
+    """The reference publishes yolov8l weights trained at 128, 256, 512, 640 and 1024 px (README.md:190-207); 256 / 512 / 640 run in the
+    other tests.  128 px: 16 / 8 / 4-px maps (narrower than every tuned patch); 1024 px: 128 / 64 / 32-px maps."""
+    base = _tile("big512")
+    big = np.concatenate([np.concatenate([base, base[:, ::-1]], 1), np.concatenate([base[::-1], base[::-1, ::-1]], 1)], 0)     # 1024 x 1024
+    imgs = [big[i * 37:i * 37 + imgsz, i * 53:i * 53 + imgsz].copy() for i in range(B)] if imgsz < 1024 else [big]
+    x, raw, _ = _oracle_forward(imgs, imgsz)
+    assert tuple(x.shape[2:]) == (imgsz, imgsz)
+    for prec, tol in (("fp16x3", 2e-4), ("fp32", 2e-4), ("fp16", 6e-2)):
+        det = detector(prec, max_batch=3, max_imgsz=1024)
+        pred = det.forward(netin_from_chw(x, det.dtype))
+        torch.cuda.synchronize()
+        err = float((pred.cpu() - raw).abs().max())
+        print("imgsz %d %s: raw head output max abs err %.3e (scale %.2f)" % (imgsz, prec, err, float(raw.abs().max())))
+        assert err <= tol * max(1.0, float(raw.abs().max())), (imgsz, prec, err)
+
+
 @pytest.mark.parametrize("scale,nc", [("n", 5), ("s", 3)])
 def test_other_scales_fp32(scale, nc):
     """yolov8n / yolov8s graphs (16..512 channels, slabs that are not multiples of 64) through the same kernels."""
