@@ -85,18 +85,23 @@ E2E_BOX_PX, E2E_SCORE = 5e-3, 2e-5
 
 
 @pytest.mark.parametrize("prec", ["fp32", "fp16x3"])
-@pytest.mark.parametrize("name,imgsz", [("big512", 512), ("galaxy", 640), ("syn192", 192)])
-def test_model_call_end_to_end_fp32(name, imgsz, prec):
+@pytest.mark.parametrize("name,imgsz,conf", [("big512", 512, 0.7), ("galaxy", 640, 0.7), ("syn192", 192, 0.7),
+                                             # the smallest and largest sizes the reference publishes weights for (README.md:190-207):
+                                             # the 512-px frame resized down by 4 / up by 2 in the letterbox (thresholds chosen on the
+                                             # oracle: 150 boxes at 128 px, where the seeded weights score <= 0.046; 300 at 1024 px
+                                             # with no candidate within 1e-5 of the threshold)
+                                             ("big512", 128, 0.04), ("big512", 1024, 0.65)])
+def test_model_call_end_to_end_fp32(name, imgsz, conf, prec):
     """The `model(image, imgsz=, conf=, iou=)` surface of caesar_yolo/evaluation.py:181-193 on the two parity contexts (exact
     fp32, and fp16x3 = fp16 high + low halves on the tuned kernels): same boxes in the same order, classes equal, boxes within
     5e-3 px, scores within 2e-5."""
     from caesar_yolo_amd.model import YOLO
     from gpu_common import seeded_weights
-    conf, iou = 0.7, 0.5
+    iou = 0.5
     img = _prep(name)
     m = oracle_model()
     d_ref, a_ref, raw, pred_ref = m.predict_raw(img, imgsz, conf, iou)
-    y = YOLO(seeded_weights()[0], precision=prec, max_batch=2, max_imgsz=640, device=0)
+    y = YOLO(seeded_weights()[0], precision=prec, max_batch=2, max_imgsz=max(640, imgsz), device=0)
     assert y.names == m.names
     r = y(img, device="cuda:0", imgsz=imgsz, conf=conf, iou=iou, save=False, visualize=False, show=False)[0]
     xyxy, cf, cl = r.boxes.xyxy.cpu().numpy(), r.boxes.conf.cpu().numpy(), r.boxes.cls.cpu().numpy()
@@ -111,7 +116,7 @@ def test_model_call_end_to_end_fp32(name, imgsz, prec):
         serr = float(np.abs(cf - d_ref[:, 4].numpy()).max()) if len(cf) else 0.0
         print("end-to-end %s %s@%d: %d boxes, max |dbox| = %.3e px (%.2e normalised), max |dscore| = %.3e"
               % (prec, name, imgsz, len(cf), berr, berr / max(H, W), serr))
-        assert berr <= E2E_BOX_PX
+        assert berr <= E2E_BOX_PX * max(1.0, imgsz / 640.0)      # (coordinates of a 1024-px network input carry 1.6x the fp32 ulp)
         assert serr <= E2E_SCORE
     else:
         pytest.skip("%d candidates within 1e-5 of the confidence threshold" % near)
