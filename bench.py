@@ -486,6 +486,11 @@ def run_rank(args):
                                    "achieved_all_launches": ((prof_all[k["kernel"]]["flops"] / (prof_all[k["kernel"]]["ms"] * 1e-3) / 1e12)
                                                              if prof_all and k["kernel"] in prof_all and prof_all[k["kernel"]]["ms"] > 0 else None),
                                    "launches_all": (prof_all[k["kernel"]]["launches"] if prof_all and k["kernel"] in prof_all else None),
+                                   "flops_per_launch_all": ((prof_all[k["kernel"]]["flops"] / prof_all[k["kernel"]]["launches"])
+                                                            if prof_all and k["kernel"] in prof_all and prof_all[k["kernel"]]["launches"] else None),
+                                   "traffic_note": "`traffic` is the PMC average over ALL launches of the kernel family in one pass (full batches "
+                                                   "and small-batch lane: the set of `launches_all` / `flops_per_launch_all`), not over the full-batch "
+                                                   "launches `achieved` is timed on: compare it with flops_per_launch_all",
                                    "achieved_exclusive": ((prof_excl[k["kernel"]]["flops"] / (prof_excl[k["kernel"]]["ms"] * 1e-3) / 1e12)
                                                           if prof_excl and k["kernel"] in prof_excl and prof_excl[k["kernel"]]["ms"] > 0 else None),
                                    "achieved_exclusive_note": "same kernel, all its launches of one full batch through the forward pass alone on the GPU "
