@@ -167,7 +167,7 @@ struct MergeArgs {          // Analyzer.process_detections on device
 };
 hipError_t launch_iou_merge(const MergeArgs& a, hipStream_t s);
 // gathered tile records -> per-tile counts / status / prefix (hdr: 3 T + 1 ints) and the valid detections in tile-id order (out)
-hipError_t launch_compact_records(const float* g, const long long* perm, int T, int stride, int* hdr, float* out, hipStream_t s);
+hipError_t launch_compact_records(const float* g, long long rows, const long long* perm, int T, int stride, int* hdr, float* out, hipStream_t s);
 
 // ---- preprocessing ---------------------------------------------------------------------------
 enum PreOp { OP_BKG = 1, OP_SHIFT = 2, OP_CLIP = 3, OP_ZSCALE = 4, OP_HISTEQ = 5, OP_MINMAX = 6 };

@@ -1193,10 +1193,10 @@ int cy_detect_flush(cy_ctx* c, void* stream) {
     return CY_OK;
 }
 
-int cy_compact_records(const float* d_gathered, const long long* d_perm, int T, int row_floats, int* d_hdr, float* d_out, void* stream) {
-    if (!d_gathered || !d_perm || !d_hdr || !d_out || T < 1 || row_floats != CY_MAX_DET * CY_DET_STRIDE + 3)
+int cy_compact_records(const float* d_gathered, long long n_rows, const long long* d_perm, int T, int row_floats, int* d_hdr, float* d_out, void* stream) {
+    if (!d_gathered || !d_perm || !d_hdr || !d_out || T < 1 || n_rows < 1 || row_floats != CY_MAX_DET * CY_DET_STRIDE + 3)
         return fail(nullptr, CY_ERR_ARG, "bad arguments");
-    const hipError_t e = launch_compact_records(d_gathered, d_perm, T, row_floats, d_hdr, d_out, (hipStream_t)stream);
+    const hipError_t e = launch_compact_records(d_gathered, n_rows, d_perm, T, row_floats, d_hdr, d_out, (hipStream_t)stream);
     if (e != hipSuccess) return fail(nullptr, CY_ERR_HIP, hipGetErrorString(e));
     return CY_OK;
 }

@@ -338,7 +338,7 @@ hipError_t launch_iou_merge(const MergeArgs& a, hipStream_t s) {
 // wants the valid detections in tile-id order on the host.  Two launches compact them on device, so that only the detections cross
 // PCIe: (1) one workgroup walks the tiles in tile-id order (perm[t] = row of tile t), writes count (0 for a rejected tile) and status
 // per tile and the exclusive prefix of the counts, (2) one workgroup per tile copies its rows to out[prefix[t] ..].
-__global__ __launch_bounds__(1024) void records_scan_kernel(const float* __restrict__ g, const long long* __restrict__ perm, int T, int stride,
+__global__ __launch_bounds__(1024) void records_scan_kernel(const float* __restrict__ g, long long rows, const long long* __restrict__ perm, int T, int stride,
                                                             int* __restrict__ hdr) {        // hdr: [T] counts | [T] status | [T] prefix | total
     __shared__ int part[1024];
     __shared__ int carry;
@@ -348,10 +348,14 @@ __global__ __launch_bounds__(1024) void records_scan_kernel(const float* __restr
         const int t = base + (int)threadIdx.x;
         int cnt = 0;
         if (t < T) {
-            const float* row = g + perm[t] * (long long)stride;
-            const int st = (int)row[stride - 2];
-            cnt = st == 0 ? (int)row[stride - 3] : 0;
-            cnt = cnt < 0 ? 0 : (cnt > 300 ? 300 : cnt);
+            const long long pr = perm[t];
+            int st = -1;                                       // (CY_ERR_ARG) a row index outside the gathered buffer: the tile counts as rejected
+            if (pr >= 0 && pr < rows) {
+                const float* row = g + pr * (long long)stride;
+                st = (int)row[stride - 2];
+                cnt = st == 0 ? (int)row[stride - 3] : 0;
+                cnt = cnt < 0 ? 0 : (cnt > 300 ? 300 : cnt);
+            }
             hdr[t] = cnt; hdr[T + t] = st;
         }
         part[threadIdx.x] = cnt;
@@ -373,15 +377,16 @@ __global__ __launch_bounds__(1024) void records_scan_kernel(const float* __restr
 __global__ __launch_bounds__(64) void records_copy_kernel(const float* __restrict__ g, const long long* __restrict__ perm, int T, int stride,
                                                           const int* __restrict__ hdr, float* __restrict__ out) {
     const int t = blockIdx.x;
-    const int n = hdr[t] * 6;
+    const int n = hdr[t] * 6;                                 // 0 for a rejected tile or a row index out of range (records_scan_kernel)
+    if (n == 0) return;
     const float* row = g + perm[t] * (long long)stride;
     float* dst = out + (long long)hdr[2 * T + t] * 6;
     for (int i = threadIdx.x; i < n; i += 64) dst[i] = row[i];
 }
 
-hipError_t launch_compact_records(const float* g, const long long* perm, int T, int stride, int* hdr, float* out, hipStream_t s) {
-    if (T < 1 || stride < 9) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(records_scan_kernel, dim3(1), dim3(1024), 0, s, g, perm, T, stride, hdr);
+hipError_t launch_compact_records(const float* g, long long rows, const long long* perm, int T, int stride, int* hdr, float* out, hipStream_t s) {
+    if (T < 1 || stride < 9 || rows < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(records_scan_kernel, dim3(1), dim3(1024), 0, s, g, rows, perm, T, stride, hdr);
     hipLaunchKernelGGL(records_copy_kernel, dim3(T), dim3(64), 0, s, g, perm, T, stride, (const int*)hdr, out);
     return hipGetLastError();
 }

@@ -109,7 +109,7 @@ def load():
                                       vp, vp, vp, vp]),
         "cy_detect_flush": (C.c_int, [vp, vp]),
         "cy_detect_fence": (C.c_int, [vp, vp]),
-        "cy_compact_records": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp]),
+        "cy_compact_records": (C.c_int, [vp, C.c_longlong, vp, C.c_int, C.c_int, vp, vp, vp]),
         "cy_detect_counters": (C.c_int, [vp, C.POINTER(C.c_longlong), C.c_int]),
         "cy_conv_bn_silu": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp, C.c_int, C.c_int, C.c_int,
                                       C.c_int, vp, vp, vp]),

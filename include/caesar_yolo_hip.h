@@ -154,10 +154,10 @@ int cy_detect_flush(cy_ctx* ctx, void* stream);
 int cy_detect_fence(cy_ctx* ctx, void* stream);
 
 /* Rank 0 after the gather (replaces the unpickling of the workers' source lists, caesar_yolo/inference.py:936-984): d_gathered holds
- * the ranks' fixed-capacity tile records, rows of row_floats = 300*6 + 3 floats {detections | count | status | tile id}; d_perm[t] =
- * row index (over all ranks) of tile t.  Writes d_hdr = {count[T] (0 for a rejected tile) | status[T] | exclusive prefix[T] | total}
+ * the ranks' fixed-capacity tile records, n_rows rows of row_floats = 300*6 + 3 floats {detections | count | status | tile id};
+ * d_perm[t] = row index (over all ranks) of tile t (an index outside [0, n_rows) makes tile t a rejected tile with status CY_ERR_ARG).  Writes d_hdr = {count[T] (0 for a rejected tile) | status[T] | exclusive prefix[T] | total}
  * (3 T + 1 ints) and the valid detections in tile-id order into d_out (room for T * 300 * 6 floats): what cy_make_tile_records takes. */
-int cy_compact_records(const float* d_gathered, const long long* d_perm, int T, int row_floats, int* d_hdr, float* d_out, void* stream);
+int cy_compact_records(const float* d_gathered, long long n_rows, const long long* d_perm, int T, int row_floats, int* d_hdr, float* d_out, void* stream);
 
 /* events the reference would not survive silently, accumulated over cy_decode_nms / cy_iou_merge / cy_detect_tiles calls:
  * out4[0] degenerate boxes (x1 >= x2 or y1 >= y2) dropped before the IoU merge -- the reference aborts on them inside

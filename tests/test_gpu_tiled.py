@@ -286,4 +286,15 @@ def test_compact_records_matches_numpy():
     assert h[3 * T] == cnt_ref.sum()
     ref = np.concatenate([flat[t, :cnt_ref[t] * 6] for t in range(T)])
     np.testing.assert_array_equal(out.cpu().numpy()[:ref.size], ref)
+    # row indices outside the gathered buffer: those tiles come back rejected (status CY_ERR_ARG, count 0), nothing is read
+    bad = perm.copy()
+    bad[[3, 1500]] = [R * rows, -7]
+    det.compact_records(gd, torch.from_numpy(bad).cuda(), hdr, out)
+    torch.cuda.synchronize()
+    h2 = hdr.cpu().numpy()
+    cnt2, st2 = cnt_ref.copy(), st_ref.copy()
+    cnt2[[3, 1500]], st2[[3, 1500]] = 0, -1          # CY_ERR_ARG
+    np.testing.assert_array_equal(h2[:T], cnt2)
+    np.testing.assert_array_equal(h2[T:2 * T], st2)
+    assert h2[3 * T] == cnt2.sum()
     det.close()
