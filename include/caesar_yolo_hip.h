@@ -26,6 +26,8 @@ enum cy_status { CY_OK = 0, CY_ERR_ARG = -1, CY_ERR_HIP = -2, CY_ERR_IO = -3, CY
 /* CY_F16: fp16 operands, fp32 accumulate (fast); CY_F32: exact fp32 FMA chains on v_mfma_f32_16x16x4_f32 (reference arithmetic,
  * slow); CY_F16X3: the fast parity context -- activations and weights carried as fp16 high + low halves (22 significand bits),
  * every product evaluated as hi*hi + lo*hi + hi*lo on the fp16 matrix cores with fp32 accumulation (3x the K of CY_F16).
+ * Range: in CY_F16 and CY_F16X3 an activation is stored through an fp16 high half, so |activation| must stay below 65504 (beyond
+ * that the value becomes inf; only CY_F32 has the fp32 range).  Weights have no such limit (scaled per output channel).
  * Buffers the caller hands to cy_forward / cy_preproc / cy_letterbox_pack / cy_conv_bn_silu are fp32 in the CY_F32 and CY_F16X3
  * contexts and fp16 in CY_F16. */
 enum cy_precision { CY_F16 = 0, CY_F32 = 1, CY_F16X3 = 2 };
