@@ -2235,7 +2235,9 @@ __global__ __launch_bounds__(512, (NB * MI <= 4 && RING == 2) ? 2 : 1) void conv
     // lines, 16 bytes of each) into every quad of lanes.  A timing-only build whose quads read 64 contiguous bytes of ONE pixel (same
     // bytes per instruction, wrong lanes) ran the 1x1 layers 1.5-9.6 % and the strided 3x3 layers 4.6-7.5 % faster (0.39 ms of the
     // 27.4 ms forward pass at batch 256); getting the data back into operand order is a 4 x 4 lane transpose per register (four
-    // ds_bpermute_b32 per load, or ~20 DPP / permlane-swap moves), which eats most of that -- not built.
+    // ds_bpermute_b32 per load, or ~20 DPP / permlane-swap moves).  Built with ds_bpermute (the next chunk's registers transposed behind
+    // the current chunk's MFMAs; bit-identical, 234 conv / forward tests green): every layer 2-14 % SLOWER (forward 28.34 vs 27.80 ms):
+    // the 16 permutes per wave and chunk cost two to three times what the better access pattern gives.  Not kept.
     const bool no_dma = CY_STAMPS_ENABLED && (a.dbg & 1), no_rd = CY_STAMPS_ENABLED && (a.dbg & 2), no_mma = CY_STAMPS_ENABLED && (a.dbg & 4),
                no_px = CY_STAMPS_ENABLED && (a.dbg & 8);
     const bool reqw = wave < NDW;
