@@ -2005,25 +2005,17 @@ __global__ __launch_bounds__(512) void conv3x3_widep_kernel(const ConvArgs a, co
         const unsigned pix0 = (unsigned)((b * H + y0 + wm * RPW) * W + xl);
         const bool okx0 = xl < W && chan_ok, okx1 = xl + 16 < W && chan_ok;
         const unsigned cb2 = (unsigned)cbase * 2u;
-        // strip form: entry of (fragment 0, this lane) -> (image, row, column) by division, the following fragments by stepping 16 entries
-        // (RS > 16: at most one row wrap per step)
-        int sb = 0, sy = 0, sx = 0;
-        if constexpr (STRIP != 0) {
-            const int e = x0 + wm * 128 + fr;
-            const int ec = e < sg.NE ? e : 0;
-            sb = strip_div(ec, sg.mIS);
-            const int r = ec - sb * sg.IS;
-            sy = strip_div(r, sg.mRS); sx = r - sy * sg.RS;
-            if (e >= sg.NE) sb = a.B;                                  // past the last image
-        }
+        // strip form: entry of (fragment mi, this lane) -> (image, row, column) by two magic divisions (any map size: the 128 entries of a
+        // wave may span several rows and, on maps of a few pixels, several images)
+        const int e0 = x0 + wm * 128 + fr;
         auto pixel = [&](int mi, unsigned& pix) -> bool {
             if constexpr (STRIP != 0) {
-                int bb = sb, yy = sy, xx = sx + 16 * mi;
-                const int rows = strip_div(xx, sg.mRS);                // whole rows stepped over (RS >= 18: at most 8 for the wave's 128 entries)
-                xx -= rows * sg.RS; yy += rows;
-                if (yy > H) { yy -= H + 1; ++bb; }                     // (an image has >= 324 entries: at most one image boundary)
+                const int e = e0 + 16 * mi;
+                const int ec = e < sg.NE ? e : 0;
+                const int bb = strip_div(ec, sg.mIS), r = ec - bb * sg.IS;
+                const int yy = strip_div(r, sg.mRS), xx = r - yy * sg.RS;
                 pix = (unsigned)((bb * H + yy) * W + xx);
-                return bb < a.B && yy < H && xx < W && chan_ok;
+                return e < sg.NE && yy < H && xx < W && chan_ok;
             } else {
                 pix = pix0 + (unsigned)((mi >> 1) * W + (mi & 1) * 16);
                 return (y0 + wm * RPW + (mi >> 1) < H) && ((mi & 1) ? okx1 : okx0);
@@ -2142,7 +2134,12 @@ static hipError_t launch_widep(const ConvArgs& a, hipStream_t s) {
 // idle share of the MFMA lanes of the 2-D patch form (16 x 32-pixel patches) and of the strip form on an H x W map
 static double wide2d_cover(int H, int W) { return (double)((H + 15) / 16 * 16) * ((W + 31) / 32 * 32) / ((double)H * W); }
 static double strip_cover(int H, int W) { return (double)(H + 1) * (W + 1) / ((double)H * W); }
-static bool strip_fits(const ConvArgs& a) { return a.Wi >= 17 && a.Hi >= 17 && a.Wi <= 126 && a.Cout % 16 == 0 && (long)a.B * (a.Hi + 1) * (a.Wi + 1) < (1L << 22); }
+// maps from 17 px wide (narrower ones down to 13 px belong to the dual-image / two-tap kernels), and the maps of a few pixels that no
+// patch shape fits (8 x 8 and 4 x 4: the stride-16 / 32 levels of 128- and 256-px inputs): 27 % / 56 % idle lanes there instead of 75 % / 94 %
+static bool strip_small(const ConvArgs& a) { return a.Wi >= 3 && a.Wi <= 12 && a.Hi >= 3 && a.Hi <= 126; }
+static bool strip_fits(const ConvArgs& a) {
+    return ((a.Wi >= 17 && a.Hi >= 17 && a.Wi <= 126) || strip_small(a)) && a.Cout % 16 == 0 && (long)a.B * (a.Hi + 1) * (a.Wi + 1) < (1L << 22);
+}
 
 static hipError_t launch_strip(const ConvArgs& a, hipStream_t s) {
     StripGeo sg;
@@ -2553,7 +2550,7 @@ int conv_variant(Precision p, const ConvArgs& a) {
         // 2 regardless of the launch size (tests); read per call.
         const int strip = env_knob("CY_STRIP", 1);
         if (wide && strip && a.wgt32 && strip_fits(a) && strip_cover(a.Hi, a.Wi) + 0.04 < wide2d_cover(a.Hi, a.Wi) &&
-            (strip > 1 || Bv * (long)(a.Hi + 1) * (a.Wi + 1) / 512 * ((pad64(a.Cout) + 127) / 128) >= 200))      // (about one strip per CU)
+            (strip > 1 || strip_small(a) || Bv * (long)(a.Hi + 1) * (a.Wi + 1) / 512 * ((pad64(a.Cout) + 127) / 128) >= 200))      // (about one strip per CU; tiny maps: every alternative idles more)
             return CONV_STRIP_128;
         const int wpad = (a.Wi + 31) / 32 * 32;
         if (wide && a.wgt32 && (wpad - a.Wi) * 8 <= a.Wi) return CONV_WIDE_128;     // <= 12.5 % of the patch columns idle
