@@ -2511,6 +2511,7 @@ static int conv_variant_x3(const ConvArgs& a) {
         const int wpad = (a.Wi + 31) / 32 * 32;
         const bool fits = (wpad - a.Wi) * 8 <= a.Wi;
         if (narrow && a.Wi % 32 == 0) return CONV_WIDE_64;
+        if (narrow && a.Cin >= 128 && env_knob("CY_STRIP", 1) && strip_small(a) && strip_fits(a)) return CONV_STRIP_128;       // (see conv_variant)
         // strip form where 16 x 32 patches would idle > 4 % more lanes (geometry only: no batch threshold in this context)
         if (!narrow && env_knob("CY_STRIP", 1) && strip_fits(a) && strip_cover(a.Hi, a.Wi) + 0.04 < wide2d_cover(a.Hi, a.Wi)) return CONV_STRIP_128;
         if (!narrow && fits) return CONV_WIDE_128;
@@ -2540,6 +2541,9 @@ int conv_variant(Precision p, const ConvArgs& a) {
         if (narrow && wide64 && a.wgt32 && a.Cin >= 128 && a.Wi % 32 == 0 && force == 0 &&
             Bv * ((a.Hi + 15) / 16) * (a.Wi / 32) >= 256)
             return CONV_WIDE_64;
+        // 64 output channels on maps of a few pixels with deep inputs (the box head of 128- / 256-px inputs): the strip form with half
+        // of its channel tile empty still beats the 16 x 16-pixel patches of the 64-channel kernels there (68 -> ~250 TFLOP/s on 4 x 4 maps)
+        if (narrow && force == 0 && a.wgt32 && a.Cin >= 128 && env_knob("CY_STRIP", 1) && strip_small(a) && strip_fits(a)) return CONV_STRIP_128;
         if (narrow && a.Cin == 64 && force != 8) return force == 9 ? CONV_GENERIC_64 : CONV_C64_PERSIST;
         if (narrow) return force == 9 ? CONV_GENERIC_64 : CONV_PP_64;
         if (force == 5) return CONV_PP_128;

@@ -244,7 +244,9 @@ def test_wide_persistent_kernel_is_bit_identical(case, monkeypatch):
                                   # maps of a few pixels (the stride-16 / 32 levels of 128- and 256-px inputs): several rows per 16-entry
                                   # fragment, several IMAGES per wave (81 / 25 entries per image), ragged 6 x 10 and 3 x 3 maps
                                   (37, 8, 8, 256, 256, True), (70, 4, 4, 512, 512, False), (9, 6, 10, 128, 192, True), (50, 3, 3, 64, 128, False),
-                                  (5, 12, 12, 128, 128, True)])
+                                  (5, 12, 12, 128, 128, True),
+                                  # 64 output channels (half of the channel tile empty): the box head on those maps
+                                  (37, 8, 8, 256, 64, False), (70, 4, 4, 512, 64, False)])
 def test_strip_form_of_the_wide_kernel(case, monkeypatch):
     """conv3x3_widep_kernel<strip>: the batch flattened to one dimension with one shared zero entry per row and one zero row per image
     (map sizes from 17 px on and the maps of 3-12 px; the 80 / 40 / 20-px maps of 640-px inputs, the 52 x 64 / 26 x 32 maps of ragged tiles, the 8 x 8 / 4 x 4 maps of 128-px inputs), forced on
@@ -276,7 +278,7 @@ def test_strip_form_of_the_wide_kernel(case, monkeypatch):
 
 @pytest.mark.parametrize("case", [(5, 80, 80, 128, 128, True), (7, 40, 40, 256, 256, False), (9, 20, 20, 512, 256, True), (3, 52, 64, 128, 128, True),
                                   (2, 33, 47, 64, 192, True), (2, 100, 126, 64, 128, False), (40, 64, 64, 128, 128, True), (3, 32, 64, 256, 256, False),
-                                  (37, 8, 8, 256, 256, True), (70, 4, 4, 512, 256, False), (9, 6, 10, 128, 192, True)])
+                                  (37, 8, 8, 256, 256, True), (70, 4, 4, 512, 256, False), (9, 6, 10, 128, 192, True), (70, 4, 4, 512, 64, False)])
 def test_fp16x3_persistent_and_strip_forms(case, monkeypatch):
     """fp16x3 context: the strip form of the persistent wide kernel (three-pass K walk over the flattened batch, scaled / split epilogue,
     residual as high + low halves requested two fragments at a time) and, with CY_X3_PERSIST=1, its 2-D form -- against F.conv2d in
