@@ -1719,6 +1719,244 @@ static hipError_t launch_wide(const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ 3x3 s1, 512 px x 128 ch, 32x32x16 MFMA
+// Round 4 A/B experiment (CY_WIDE_MFMA=32): conv3x3_wide_kernel<true, 2> with its K loop on v_mfma_f32_32x32x16_f16 instead of
+// v_mfma_f32_16x16x32_f16 -- the same workgroup (16 x 32 px x 128 ch), wave tile (128 px x 64 ch = 4 x 2 blocks of 32 x 32, 128
+// accumulator registers), stage stream (halo x2, 3-slot weight ring, two taps per barrier, counted vmcnt, tail MFMAs behind the
+// barrier) and the same packed weights; half as many MFMA instructions, each holding the SIMD's vector issue for 8 of its 32 cycles
+// instead of 8 of 16.  A lane's fragment is (row lane & 31, 8 channels of K-step s at chunk 2 s + (lane >> 5)), so the 16 lanes of a
+// ds_read_b128 group read ONE chunk of 16 rows: the swizzle has to spread a row's chunk over all four 16-byte slots,
+// chunk' = chunk ^ f with f = (rx >> 2) & 3 of the halo column rx (not of the linear row index: a tap then shifts the lane's row by a
+// compile-time constant and only kw changes f -> six lane bases for the pixels, two for the weights), f = (row >> 4) & 3 for the
+// weight rows.  Weight rows are read through the permutation that makes a lane's 16 accumulator registers of a block 16 contiguous
+// output channels on the 16x16-ordered packed copy: MFMA row m of block ni <- packed row 16 (m >> 3) + 8 ni + 4 ((m >> 2) & 1) + (m & 3).
+// SCHED = 1: the fragment reads of the next K-step are spread between the MFMAs of the current one (one ds_read_b128 per 32-cycle
+// MFMA, sched_group_barrier) instead of wherever the compiler sinks them (in front of the last MFMA of the group, latency exposed).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int SCHED>
+__global__ __launch_bounds__(512) void conv3x3_wide32_kernel(const ConvArgs a) {
+    constexpr int NST = 9, TH = 16, TW = 32, NW = 8, BN = 128, PWID = TW + 2, RPW = 4;
+    constexpr int PR = (TH + 2) * PWID, NPC = (PR + 15) / 16, PROUNDS = (NPC + NW - 1) / NW;
+    constexpr int P_BYTES = PROUNDS * NW * 1024, SLAB = BN * 64, W_BYTES = 2 * SLAB, RING = 3, WPS = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const Pbuf = smem;
+    char* const Wbuf = smem + 2 * P_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int H = a.Hi, W = a.Wi;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int cpad = pad128(a.Cout);
+    const int ntn = (pad64(a.Cout) + BN - 1) / BN;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = id % ntn;
+    int rest = id / ntn;
+    const int tx = rest % tiles_x; rest /= tiles_x;
+    const int ty = rest % tiles_y;
+    const int b = rest / tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW, n0 = nt * BN;
+    const int pairs = a.Cin / 64;
+
+    const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in0), 0, a.in0_bytes, 0x00020000);
+    const auto rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wgt32), 0, a.wgt32_bytes, 0x00020000);
+    unsigned poff[PROUNDS];
+#pragma unroll
+    for (int j = 0; j < PROUNDS; ++j) {
+        const int r = (j * NW + wave) * 16 + (lane >> 2);
+        const int ry = r / PWID, rx = r - ry * PWID;
+        const int y = y0 + ry - 1, x = x0 + rx - 1;
+        const int q = (lane & 3) ^ ((rx >> 2) & 3);
+        const bool ok = r < PR && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+        poff[j] = ok ? (unsigned)(((b * H + y) * W + x) * a.in0_ct + a.in0_coff + q * 8) * 2u : CY_OOB;
+    }
+    unsigned woff;
+    {
+        const int row = wave * 16 + (lane >> 2);
+        woff = (unsigned)((n0 + row) * 64 + ((lane & 3) ^ ((row >> 4) & 3)) * 16);
+    }
+    auto dma_patch = [&](int buf, int slab) {
+#pragma unroll
+        for (int j = 0; j < PROUNDS; ++j)
+            dma_piece(rs0, (lds_ptr_t*)(Pbuf + buf * P_BYTES + (j * NW + wave) * 1024), poff[j], (unsigned)slab * 64u);
+    };
+    auto dma_stage = [&](int ring, int slab0, int u0) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int u = u0 + t, sl = slab0 + u / 9, tap = u % 9;
+            dma_piece(rsw, (lds_ptr_t*)(Wbuf + ring * W_BYTES + t * SLAB + wave * 1024), woff, (sl * 9 + tap) * cpad * 64);
+        }
+    };
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[ni][mi][j] = 0.f;
+    const int lr = lane & 31, lh = lane >> 5;
+    unsigned pbx[6], wlx[2];
+    const int rw0 = wm * RPW * PWID;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            pbx[kw * 2 + s] = (unsigned)((rw0 + kw + lr) * 64 + (((2 * s + lh) ^ (((kw + lr) >> 2) & 3)) << 4));
+    {
+        const int p0 = 16 * (lr >> 3) + 4 * ((lr >> 2) & 1) + (lr & 3);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) wlx[s] = (unsigned)(2 * P_BYTES + (wn * 64 + p0) * 64 + (((2 * s + lh) ^ (lr >> 3)) << 4));
+    }
+    f16x8 wa[2][2], xb[2][4];
+    auto load_k = [&](int bi, int pbuf_off, int wbuf_off, int kh, int kw, int s) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) wa[bi][ni] = *reinterpret_cast<const f16x8*>(smem + wlx[s] + (wbuf_off + ni * 512));
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) xb[bi][mi] = *reinterpret_cast<const f16x8*>(smem + pbx[kw * 2 + s] + (pbuf_off + (mi + kh) * PWID * 64));
+    };
+    auto mma = [&](int bi) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[bi][ni], xb[bi][mi], acc[ni][mi], 0, 0, 0);
+    };
+    auto stage_compute = [&](int st) {
+        const int u0 = 2 * st, u1 = u0 + 1, t0 = u0 % 9, t1 = u1 % 9;
+        const int p0 = (u0 / 9) * P_BYTES, p1 = (u1 / 9) * P_BYTES, w0 = (st % 3) * W_BYTES, w1 = w0 + SLAB;
+        load_k(0, p0, w0, t0 / 3, t0 % 3, 0);
+        load_k(1, p0, w0, t0 / 3, t0 % 3, 1);
+        mma(0);
+        if constexpr (SCHED != 0) {                          // region = [tail MFMAs of the previous stage, 12 reads, 8 MFMAs]
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); }
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        load_k(0, p1, w1, t1 / 3, t1 % 3, 0);
+        mma(1);
+        if constexpr (SCHED != 0) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        load_k(1, p1, w1, t1 / 3, t1 % 3, 1);
+        mma(0);
+        if constexpr (SCHED != 0) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);                  // the last 8 MFMAs of the stage are issued behind the stage barrier
+    };
+
+    float* const bias_lds = reinterpret_cast<float*>(smem + 2 * P_BYTES + RING * W_BYTES);
+    if (wave == 0) {
+        const auto rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, (unsigned)pad64(a.Cout) * 4u, 0x00020000);
+        dma_piece(rsb, (lds_ptr_t*)bias_lds, lane * 16 < BN * 4 ? (unsigned)(n0 * 4 + lane * 16) : CY_OOB, 0);
+    }
+    dma_patch(0, 0);
+    dma_stage(0, 0, 0);
+    dma_stage(1, 0, 2);
+    CY_WAIT_VM(WPS);
+    __builtin_amdgcn_s_barrier();
+#pragma unroll 1
+    for (int cp = 0; cp < pairs; ++cp) {
+        const bool more = cp + 1 < pairs;
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+            const bool has_w = st + 2 < NST || more;
+            if (st + 2 < NST) dma_stage((st + 2) % 3, 2 * cp, 2 * (st + 2));
+            else if (more) dma_stage((st + 2) % 3, 2 * cp + 2, 2 * (st + 2 - NST));
+            if (st == 0) dma_patch(1, 2 * cp + 1);
+            if (st == 5 && more) dma_patch(0, 2 * cp + 2);
+            stage_compute(st);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (st == 0 || st == 1) { CY_WAIT_VM(WPS + PROUNDS); }
+            else if (st == 5 || st == 6) { if (more) { CY_WAIT_VM(WPS + PROUNDS); } else { CY_WAIT_VM(WPS); } }
+            else if (has_w) { CY_WAIT_VM(WPS); }
+            else { CY_WAIT_VM(0); }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            mma(1);
+        }
+    }
+
+    // epilogue: lane (lr, lh) holds, per block (ni, mi), channels n0 + wn*64 + ni*32 + lh*16 + 0..15 of pixel (y0 + wm*4 + mi, x0 + lr)
+    const int x = x0 + lr;
+    const auto rsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.res ? a.res : a.in0), 0,
+                                                       a.res ? (unsigned)((long)a.B * H * W * a.res_ct * 2) : 0u, 0x00020000);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int cl = wn * 64 + ni * 32 + lh * 16, cbase = n0 + cl;
+        const bool vec = cbase + 16 <= a.Cout, res_vec = a.res != nullptr && vec;
+        f16x8 rv[4][2];
+        if (res_vec) {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int y = y0 + wm * RPW + mi;
+                const bool ok = y < H && x < W;
+                const unsigned ro = ok ? (unsigned)((((b * H + y) * W + x) * a.res_ct + a.res_coff + cbase) * 2) : CY_OOB;
+                rv[mi][0] = __builtin_bit_cast(f16x8, load_b128(rsr, ro, 0));
+                rv[mi][1] = __builtin_bit_cast(f16x8, load_b128(rsr, ro, 16));
+            }
+        }
+        float bv[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(bias_lds + cl + j * 4);
+            bv[j * 4] = t[0]; bv[j * 4 + 1] = t[1]; bv[j * 4 + 2] = t[2]; bv[j * 4 + 3] = t[3];
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int y = y0 + wm * RPW + mi;
+            if (y >= H || x >= W) continue;
+            const long pix = ((long)b * H + y) * W + x;
+            const f32x16& c = acc[ni][mi];
+            float v[16];
+            bias_act16(f32x4{c[0], c[1], c[2], c[3]}, f32x4{c[4], c[5], c[6], c[7]}, f32x4{c[8], c[9], c[10], c[11]},
+                       f32x4{c[12], c[13], c[14], c[15]}, bv, a.act != 0, v);
+            if (vec) {
+                f16* dst = reinterpret_cast<f16*>(a.out) + pix * a.out_ct + a.out_coff + cbase;
+                if (res_vec) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { v[j] += (float)rv[mi][0][j]; v[8 + j] += (float)rv[mi][1][j]; }
+                }
+                f16x8 o0, o1;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { o0[j] = (f16)v[j]; o1[j] = (f16)v[8 + j]; }
+                *reinterpret_cast<f16x8*>(dst) = o0;
+                *reinterpret_cast<f16x8*>(dst + 8) = o1;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int ch = cbase + j;
+                    if (ch >= a.Cout) continue;
+                    float t = v[j];
+                    if (a.res) t += (float)(reinterpret_cast<const f16*>(a.res)[pix * a.res_ct + a.res_coff + ch]);
+                    reinterpret_cast<f16*>(a.out)[pix * a.out_ct + a.out_coff + ch] = (f16)t;
+                }
+            }
+        }
+    }
+}
+
+template <int SCHED>
+static hipError_t launch_wide32(const ConvArgs& a, hipStream_t s) {
+    constexpr int PR = 18 * 34, NPC = (PR + 15) / 16, PROUNDS = (NPC + 7) / 8;
+    const size_t lds = 2 * PROUNDS * 8 * 1024 + 3 * 2 * 128 * 64 + 1024;        // halo x2, weight ring, bias
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wide32_kernel<SCHED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int blocks = a.B * ((a.Wi + 31) / 32) * ((a.Hi + 15) / 16) * ((pad64(a.Cout) + 127) / 128);
+    hipLaunchKernelGGL(conv3x3_wide32_kernel<SCHED>, dim3(blocks), dim3(512), lds, s, a);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ 3x3 s1, 512 px x 128 ch, persistent
 // conv3x3_wide_kernel<true, 2> as ONE workgroup per CU walking the patches (patch n of a workgroup = blockIdx.x + n * gridDim.x
 // in the same XCD-aware order).  What a one-patch workgroup pays outside its stage loop -- per-workgroup records of the stamped
@@ -2618,6 +2856,8 @@ hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s) {
             ConvArgs b2 = a; b2.dbg = dev_knob("CY_DBG", 0);
             // persistent form (same arithmetic in the same order: bit-identical outputs) when every CU gets at least two patches
             // and the output tile has whole 16-channel groups; CY_WIDE_PERSIST: 0 off, 2 regardless of the launch size (tests)
+            // round-4 A/B: the K loop on 32x32x16 MFMAs (32: compiler-placed fragment reads, 33: one read per MFMA gap)
+            if (const int mf = env_knob("CY_WIDE_MFMA", 16); mf >= 32) return mf == 33 ? launch_wide32<1>(b2, s) : launch_wide32<0>(b2, s);
             const int wp = env_knob("CY_WIDE_PERSIST", 1);
             const long patches = (long)a.B * ((a.Wi + 31) / 32) * ((a.Hi + 15) / 16) * ((pad64(a.Cout) + 127) / 128);
             // Measured per layer at batch 256: 18-stage layers (Cin 128: model.4 / model.15 bottlenecks) -4..-6 %, 36-stage ones

@@ -238,6 +238,38 @@ def test_wide_persistent_kernel_is_bit_identical(case, monkeypatch):
         assert torch.equal(ref, got)
 
 
+@pytest.mark.parametrize("mf", ["32", "33"])
+@pytest.mark.parametrize("case", [(3, 64, 64, 128, 128, True), (2, 40, 64, 256, 192, True), (33, 40, 60, 128, 256, False), (1, 16, 32, 64, 128, False),
+                                  (2, 30, 60, 64, 256, True), (5, 32, 32, 512, 256, False)])
+def test_wide_kernel_on_32x32x16_mfma(case, mf, monkeypatch):
+    """conv3x3_wide32_kernel (round 4 A/B: the wide kernel's K loop on v_mfma_f32_32x32x16_f16; CY_WIDE_MFMA=32 compiler-placed
+    fragment reads, 33 one read per MFMA gap): against F.conv2d on fp16-rounded inputs (K is summed 16 channels per instruction
+    instead of 32, so not bit-identical to the 16x16x32 kernel), ragged rows / columns / channel tiles, residual, repeatable."""
+    monkeypatch.setenv("CY_WIDE_MFMA", mf)
+    monkeypatch.setenv("CY_STRIP", "0")           # ragged maps would otherwise take the strip form
+    B, H, W, Cin, Cout, use_res = case
+    det = detector("fp16", max_batch=4)
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn((B, Cin, H, W), generator=g).half().float()
+    w = (torch.randn((Cout, Cin, 3, 3), generator=g) / (Cin * 9) ** 0.5).half().float()
+    b = torch.randn((Cout,), generator=g) * 0.1
+    y = F.silu(F.conv2d(x, w, b, padding=1))
+    res = None
+    if use_res:
+        res = torch.randn(y.shape, generator=g).half().float()
+        y = y + res
+    xd = x.permute(0, 2, 3, 1).contiguous().half().cuda()
+    rd = res.permute(0, 2, 3, 1).contiguous().half().cuda() if use_res else None
+    out = det.conv_bn_silu(xd, w.numpy(), b.numpy(), 3, 1, True, rd)
+    torch.cuda.synchronize()
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    scale = max(float(y.abs().max()), 1.0)
+    err = float((got - y).abs().max())
+    assert err <= 4e-3 * scale, "max abs err %.3e (scale %.2f)" % (err, scale)
+    for _ in range(4):
+        assert torch.equal(out, det.conv_bn_silu(xd, w.numpy(), b.numpy(), 3, 1, True, rd))
+
+
 @pytest.mark.parametrize("case", [(5, 80, 80, 128, 128, True), (7, 40, 40, 256, 256, False), (9, 20, 20, 512, 512, True), (3, 52, 64, 128, 128, True),
                                   (4, 26, 32, 256, 192, False), (2, 33, 47, 64, 128, True), (1, 17, 95, 128, 144, False), (13, 20, 20, 128, 128, False),
                                   (2, 100, 126, 64, 128, True),
