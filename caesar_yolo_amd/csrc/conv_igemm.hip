@@ -1324,8 +1324,10 @@ static hipError_t launch_halo2(const ConvArgs& a, hipStream_t s) {
 // per wave and stage, 32 MFMAs per wave between barriers.
 // DUAL = true: maps at most 16 pixels wide (the stride-32 level of a 512-px tile): the 32 patch columns are the 16 columns of
 // TWO consecutive images, each with its own left/right halo column (patch rows of 36 instead of 34 pixels).
-template <bool TAIL, int WN, bool DUAL = false, int TPS = 2, bool SPLIT = false>
+template <bool TAIL, int WN, bool DUAL = false, int TPS = 2, bool SPLIT = false, int SCHED = 0>
 __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
+    // SCHED = 1 (round 4 experiment, CY_WIDE_SCHED=1): the eight fragment reads of a half-step are spread between the 16 MFMAs of the
+    // previous one (sched_group_barrier: one ds_read_b128 per two MFMAs) instead of where the compiler sinks them
     // SPLIT (fp16x3 context): three passes over the input channels -- halo slabs of [x_lo | x_hi | x_hi] against the weight
     // slabs [w_hi | w_lo | w_hi] of the packed copy, i.e. the same stage loop over 3x the slab pairs; scaled / split epilogue
     // TPS = taps per stage (between two barriers): 2, or 3 (WN = 2 only: six stages of 96 MFMAs per slab pair, 152 KiB of LDS)
@@ -1468,13 +1470,27 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
             load_x(xa[0], p0, t0 / 3, t0 % 3, 0);
             load_x(xa[1], p0, t0 / 3, t0 % 3, 1);
             mma(wb[0], xa[0], 0);
+            if constexpr (SCHED != 0 && TAIL) {              // region = [tail MFMAs of the previous stage, 12 reads, 16 MFMAs]
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); }
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
             load_w(wb[1], w1);
             load_x(xa[0], p1, t1 / 3, t1 % 3, 0);
             mma(wb[0], xa[1], 1);
+            if constexpr (SCHED != 0) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); }
+            }
             __builtin_amdgcn_sched_barrier(0);
             load_x(xa[1], p1, t1 / 3, t1 % 3, 1);
             mma(wb[1], xa[0], 0);
+            if constexpr (SCHED != 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); }
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (!TAIL) mma(wb[1], xa[1], 1);                 // TAIL: the last 16 MFMAs are issued behind the stage barrier
         } else {                                             // one half-step (4 fragments = this wave's 64 pixels) per tap
@@ -1701,21 +1717,21 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
     }
 }
 
-template <int WN, bool DUAL = false, int TPS = 2, bool SPLIT = false>
+template <int WN, bool DUAL = false, int TPS = 2, bool SPLIT = false, int SCHED = 0>
 static hipError_t launch_wide(const ConvArgs& a, hipStream_t s) {
     constexpr int PR = 18 * (DUAL ? 36 : 34), NPC = (PR + 15) / 16, PROUNDS = (NPC + 7) / 8, BN = 64 * WN;
     const size_t lds = 2 * PROUNDS * 8 * 1024 + 3 * TPS * BN * 64 + 1024;       // halo x2, weight ring, bias
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wide_kernel<false, WN, DUAL, TPS, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wide_kernel<true, WN, DUAL, TPS, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wide_kernel<false, WN, DUAL, TPS, SPLIT, SCHED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wide_kernel<true, WN, DUAL, TPS, SPLIT, SCHED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const int bx = DUAL ? (a.B + 1) / 2 : a.B * ((a.Wi + 31) / 32);
     const int blocks = bx * ((a.Hi + 15) / 16) * ((pad64(a.Cout) + BN - 1) / BN);
     static const int tail = getenv("CY_WIDE_TAIL") ? atoi(getenv("CY_WIDE_TAIL")) : 1;
-    if (tail) hipLaunchKernelGGL((conv3x3_wide_kernel<true, WN, DUAL, TPS, SPLIT>), dim3(blocks), dim3(512), lds, s, a);
-    else hipLaunchKernelGGL((conv3x3_wide_kernel<false, WN, DUAL, TPS, SPLIT>), dim3(blocks), dim3(512), lds, s, a);
+    if (tail) hipLaunchKernelGGL((conv3x3_wide_kernel<true, WN, DUAL, TPS, SPLIT, SCHED>), dim3(blocks), dim3(512), lds, s, a);
+    else hipLaunchKernelGGL((conv3x3_wide_kernel<false, WN, DUAL, TPS, SPLIT, SCHED>), dim3(blocks), dim3(512), lds, s, a);
     return hipGetLastError();
 }
 
@@ -2863,6 +2879,7 @@ hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s) {
             // Measured per layer at batch 256: 18-stage layers (Cin 128: model.4 / model.15 bottlenecks) -4..-6 %, 36-stage ones
             // -1.7..+1.5 %: taken for up to two slab pairs.
             if (wp && tps == 2 && a.Cout % 16 == 0 && (wp > 1 || (patches >= 512 && a.Cin <= 128))) return launch_widep(b2, s);
+            if (tps == 2 && env_knob("CY_WIDE_SCHED", 0)) return launch_wide<2, false, 2, false, 1>(b2, s);      // round-4 experiment: reads interleaved with the MFMAs
             return tps == 3 ? launch_wide<2, false, 3>(b2, s) : launch_wide<2>(b2, s);
         }
         case CONV_STRIP_128: return launch_strip(a, s);

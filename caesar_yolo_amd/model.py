@@ -51,7 +51,7 @@ def _dev_index(device):
 class HipDetector(object):
     """One library context on one GPU.  Thin, explicit wrappers over the C-ABI stage entry points."""
 
-    def __init__(self, weights_path, device=0, precision="fp16", max_batch=64, max_imgsz=640, max_cand=0):
+    def __init__(self, weights_path, device=0, precision="fp16x3", max_batch=64, max_imgsz=640, max_cand=0):
         self.lib = L.load()
         if not torch.cuda.is_available():
             raise L.CyError("no GPU visible: the HIP detector cannot run (no CPU fallback exists)")

@@ -76,8 +76,10 @@ def parse_args(argv=None):
     p.add_argument('--detect_outfile', type=str, default="")
     p.add_argument('--detect_outfile_json', type=str, default="")
     p.add_argument('--precision', type=str, default="fp16x3", choices=["fp16", "fp16x3", "fp32"],
-                   help='fp32 (default): exact-fp32 kernels, detections match the reference CPU run to 1e-4; fp16: fp16 operands / '
-                        'fp32 accumulate, ~16x the throughput, 2-3 %% of the detections differ (DESIGN.md section 2)')
+                   help='arithmetic of the detector.  fp16x3 (default): parity context -- activations and weights as fp16 high + low halves, '
+                        'fp32 accumulate; kept boxes identical to the fp32 oracle, boxes within 1e-4 of the image size (<= 0.06 px), scores 2e-5.  '
+                        'fp32: exact fp32 FMA chains (the reference\'s own arithmetic), ~2.7x slower than fp16x3.  fp16: throughput mode, fp16 '
+                        'operands / fp32 accumulate, ~3x the fp16x3 rate; 2-4 %% of the detections differ from the fp32 run (DESIGN.md section 2)')
     p.add_argument('--tile_batch', type=int, default=64)
     return p.parse_args(argv)
 

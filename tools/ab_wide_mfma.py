@@ -15,8 +15,9 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 ROUNDS = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 SETTINGS = [("16x16x32 shipped", {}), ("16x16x32 one-patch", {"CY_WIDE_PERSIST": "0"}),
-            ("32x32x16", {"CY_WIDE_MFMA": "32"}), ("32x32x16 sched", {"CY_WIDE_MFMA": "33"})]
-KEYS = ["CY_WIDE_PERSIST", "CY_WIDE_MFMA"]
+            ("32x32x16", {"CY_WIDE_MFMA": "32"}), ("32x32x16 sched", {"CY_WIDE_MFMA": "33"}),
+            ("16x16x32 one-patch sched", {"CY_WIDE_PERSIST": "0", "CY_WIDE_SCHED": "1"})]
+KEYS = ["CY_WIDE_PERSIST", "CY_WIDE_MFMA", "CY_WIDE_SCHED"]
 m = YOLO("seeded:l:5", precision="fp16", max_batch=B, max_imgsz=H, device=0)
 det = m.engine(0)
 x = torch.rand((B, H, H, 4), device="cuda").half()
@@ -65,4 +66,4 @@ for ln in base["layers"]:
         lay[ln] = v
 out["layers_ms"] = lay
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "ab_wide_mfma_B%d_%d.json" % (B, H)), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "ab_wide_mfma_B%d_%d%s.json" % (B, H, os.environ.get("AB_TAG", ""))), "w"), indent=1)
