@@ -180,7 +180,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_ige
     const int m0 = (id / ntn) * BM, n0 = (id % ntn) * BN;
     const int taps = a.k * a.k, cpad = pad128(a.Cout);
     const int pchunks = (a.Cin + BKE - 1) / BKE;             // K chunks of one pass over the input channels
-    const int cchunks = SPLIT ? 3 * pchunks : pchunks;       // fp16x3: three passes (x_lo w_hi, x_hi w_lo, x_hi w_hi)
+    const int cchunks = SPLIT ? a.split * pchunks : pchunks; // fp16x3: three passes (x_lo w_hi, x_hi w_lo, x_hi w_hi), or two (x_lo w, x_hi w: fp16-exact weights)
     const int nslab = taps * cchunks;
 
     const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in0), 0, a.in0_bytes, 0x00020000);
@@ -1356,7 +1356,7 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const ConvArgs a) {
     const int b = rest / tiles_y;
     const int y0 = ty * TH, x0 = tx * TW, n0 = nt * BN;
     const int ppairs = a.Cin / 64;                          // pairs of 32-channel slabs in one pass over the input channels
-    const int pairs = SPLIT ? 3 * ppairs : ppairs;
+    const int pairs = SPLIT ? a.split * ppairs : ppairs;     // a.split = passes of the fp16x3 context (3, or 2 for fp16-exact weights)
     const bool stamps = CY_STAMPS_ENABLED && (a.dbg & 64) != 0;      // diagnostic builds: phase stamps of the workgroup
     const unsigned long long t_entry = stamps ? stamp_real() : 0;
 
@@ -2020,7 +2020,7 @@ __global__ __launch_bounds__(512) void conv3x3_widep_kernel(const ConvArgs a, co
     const int cpad = pad128(a.Cout);
     const int ntn = (pad64(a.Cout) + BN - 1) / BN;
     const int ppairs = a.Cin / 64;                          // slab pairs of one pass over the input channels
-    const int pairs = SPLIT ? 3 * ppairs : ppairs;
+    const int pairs = SPLIT ? a.split * ppairs : ppairs;     // a.split = passes of the fp16x3 context (3, or 2 for fp16-exact weights)
     const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in0), 0, a.in0_bytes, 0x00020000);
     const auto rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wgt32), 0, a.wgt32_bytes, 0x00020000);
     const auto rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, (unsigned)pad64(a.Cout) * 4u, 0x00020000);
@@ -2440,7 +2440,7 @@ __global__ __launch_bounds__(512, (NB * MI <= 4 && RING == 2) ? 2 : 1) void conv
     // K3 = false is the plain 1x1 kernel: none of the tap arithmetic is compiled in.
     constexpr int taps = K3 ? 9 : 1, pad = K3 ? 1 : 0, kk3 = K3 ? 3 : 1;
     const int pchunks = (a.Cin / 64) * taps, c0chunks = a.c1 ? a.c0 / 64 : pchunks;     // chunks of one pass; of its first segment
-    const int chunks = SPLIT ? 3 * pchunks : pchunks;
+    const int chunks = SPLIT ? a.split * pchunks : pchunks;
     const unsigned bias_bytes = K3 ? (unsigned)((a.Wi + 1) * a.in0_ct) * 2u : 0u;
 
     // (num_records widened by the bias so that the check passes whether or not the hardware adds soffset before it)
@@ -2841,7 +2841,7 @@ int conv_variant(Precision p, const ConvArgs& a) {
 
 hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s) {
     if (p == PREC_F16X3) {
-        if (!a.split || !a.oscale) return hipErrorInvalidValue;
+        if ((a.split != 2 && a.split != 3) || !a.oscale) return hipErrorInvalidValue;
         switch (conv_variant_x3(a)) {
             case CONV_WIDE_128:      // persistent form (bit-identical) with CY_X3_PERSIST=1: measured before it became a default
                 if (env_knob("CY_X3_PERSIST", 0) && a.Cout % 16 == 0) return launch_widep(a, s);
@@ -2960,20 +2960,52 @@ void pack_weights(Precision p, const float* W, int cout, int cin, int k, void* d
 // halves w_lo = fp16(w' - fp16(w')) of all but vanishing weights are then normal fp16 numbers (unscaled they would sit in the
 // subnormal range and carry ~3e-6 relative error); oscale[n] = 2^-e(n) multiplies the accumulator in the epilogue (exact).
 // K holds three passes over the (chunk-padded) input channels: w_hi, w_lo, w_hi -- against x_lo, x_hi, x_hi (see x3_chunk).
-size_t packed_weight_bytes_x3(int cout, int cin, int k, int chunk_bytes) {
-    const int epb = chunk_bytes / 2;
-    return packed_weight_bytes(PREC_F16, cout, 3 * ((cin + epb - 1) / epb * epb), k, chunk_bytes);
+// TWO passes (round 4) when every weight of the layer is an fp16 value times its channel's scale, exactly: W[n] = fl32(w16[n] * scale[n])
+// with w16 representable in fp16 -- what an ultralytics checkpoint is (its tensors are stored in fp16; Conv + BatchNorm are folded in
+// fp32 at load time, so the folded filter of channel n is the fp16 filter times gamma / sqrt(var + eps)).  The layer is then
+// scale[n] * sum_k (x_lo + x_hi) * w16: K holds [w16 | w16] against [x_lo | x_hi], oscale[n] = scale[n], and the weights carry no
+// rounding at all.  x3_passes() decides from the numbers themselves (scale = null: all ones).
+int x3_passes(const float* W, int cout, int cin, int k, const float* scale) {
+    const size_t per = (size_t)cin * k * k;
+    for (int n = 0; n < cout; ++n) {
+        const float sc = scale ? scale[n] : 1.0f;
+        if (!(sc != 0.0f) || !std::isfinite(sc)) return 3;
+        for (size_t i = 0; i < per; ++i) {
+            const float w = W[(size_t)n * per + i];
+            const f16 h = (f16)(w / sc);
+            if (!((float)h * sc == w)) return 3;
+        }
+    }
+    return 2;
 }
 
-void pack_weights_x3(const float* W, int cout, int cin, int k, void* dst, float* oscale, int chunk_bytes) {
+size_t packed_weight_bytes_x3(int cout, int cin, int k, int chunk_bytes, int passes) {
+    const int epb = chunk_bytes / 2;
+    return packed_weight_bytes(PREC_F16, cout, passes * ((cin + epb - 1) / epb * epb), k, chunk_bytes);
+}
+
+void pack_weights_x3(const float* W, int cout, int cin, int k, void* dst, float* oscale, int chunk_bytes, int passes, const float* scale) {
     const int taps = k * k, epb = chunk_bytes / 2, cinp = (cin + epb - 1) / epb * epb, cp = pad128(cout);
-    memset(dst, 0, packed_weight_bytes_x3(cout, cin, k, chunk_bytes));
+    memset(dst, 0, packed_weight_bytes_x3(cout, cin, k, chunk_bytes, passes));
     for (int i = 0; i < cp; ++i) oscale[i] = 1.0f;
     f16* o = reinterpret_cast<f16*>(dst);
     for (int row = 0; row < cp; ++row) {
         const int blk = row >> 6, ni = (row >> 4) & 3, rr = row & 15;
         const int n = blk * 64 + (rr >> 2) * 16 + ni * 4 + (rr & 3);      // channel held by packed row `row`
         if (n >= cout) continue;
+        if (passes == 2) {                                   // exact fp16 filter, the channel's scale in the epilogue
+            const float sc = scale ? scale[n] : 1.0f;
+            oscale[n] = sc;
+            for (int t = 0; t < taps; ++t)
+                for (int c = 0; c < cin; ++c) {
+                    const f16 h = (f16)(W[((size_t)n * cin + c) * taps + t] / sc);
+                    for (int pass = 0; pass < 2; ++pass) {
+                        const int cv = pass * cinp + c;
+                        o[(((size_t)(cv / epb) * taps + t) * cp + row) * epb + (cv % epb)] = h;
+                    }
+                }
+            continue;
+        }
         float m = 0.0f;
         for (size_t i = 0; i < (size_t)cin * taps; ++i) m = fmaxf(m, fabsf(W[(size_t)n * cin * taps + i]));
         int e = 0;

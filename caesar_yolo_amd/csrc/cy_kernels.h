@@ -42,7 +42,7 @@ struct ConvArgs {
     int B, Hi, Wi, Ho, Wo, Cin, Cout, k, s, act;
     uint32_t in0_bytes, in1_bytes, wgt_bytes;          // buffer extents for the hardware range check
     int dbg;                                           // developer ablation bits (0 in production)
-    // fp16x3 context (split != 0): *_ct are in halves (2 * channels of the tensor); the low halves of a slice sit *_lo halves behind
+    // fp16x3 context (split = passes over K: 3, or 2 when the layer's weights are fp16-exact up to a per-channel scale; 0 elsewhere): *_ct are in halves (2 * channels of the tensor); the low halves of a slice sit *_lo halves behind
     // its high halves.  wgt / wgt32 then hold 3 passes over K: [w_hi | w_lo | w_hi] against inputs [x_lo | x_hi | x_hi]; oscale[n] is
     // the power of two that undoes the weight scale of output channel n (applied to the accumulator before the bias).
     int split, in0_lo, in1_lo, out_lo, res_lo;
@@ -119,9 +119,12 @@ hipError_t launch_pool5(Precision p, const PoolArgs& a, hipStream_t s);
 //   so that MFMA row (ni, rr) holds channel 64*blk + 16*(rr>>2) + 4*ni + (rr&3).
 size_t packed_weight_bytes(Precision p, int cout, int cin, int k, int chunk_bytes = 128);
 void pack_weights(Precision p, const float* W, int cout, int cin, int k, void* dst, int chunk_bytes = 128);
-// fp16x3 context: scaled [hi | lo | hi] passes (each pass padded to whole K chunks); oscale: [pad128(cout)] floats, 2^-s per channel
-size_t packed_weight_bytes_x3(int cout, int cin, int k, int chunk_bytes = 128);
-void pack_weights_x3(const float* W, int cout, int cin, int k, void* dst, float* oscale, int chunk_bytes = 128);
+// fp16x3 context: scaled [hi | lo | hi] passes (each pass padded to whole K chunks); oscale: [pad128(cout)] floats, 2^-s per channel.
+// passes = 2: [w16 | w16] of a filter that is exactly fp16 values times a per-channel scale (oscale = scale); x3_passes() tells which
+// form a layer admits (scale: [cout] or null = ones).
+int x3_passes(const float* W, int cout, int cin, int k, const float* scale);
+size_t packed_weight_bytes_x3(int cout, int cin, int k, int chunk_bytes = 128, int passes = 3);
+void pack_weights_x3(const float* W, int cout, int cin, int k, void* dst, float* oscale, int chunk_bytes = 128, int passes = 3, const float* scale = nullptr);
 // fp32 NHWC [npix][C] <-> high/low halves [npix][2C] (test entry cy_conv_bn_silu, debug reads)
 hipError_t launch_x3_split(const float* in, void* out, long npix, int C, hipStream_t s);
 hipError_t launch_x3_merge(const void* in, float* out, long npix, int C, hipStream_t s);

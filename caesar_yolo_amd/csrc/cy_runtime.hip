@@ -14,6 +14,7 @@ using namespace cy;
 
 struct DevConv { void* w = nullptr; float* bias = nullptr; size_t wbytes = 0; float* stem_w = nullptr; void* w32 = nullptr; size_t w32bytes = 0;
                  float* oscale = nullptr;       // fp16x3 context: 2^-e per output channel (undoes the weight scale in the epilogue)
+                 int passes = 3;                // fp16x3 context: passes over K -- 3, or 2 when the filter is fp16-exact up to a per-channel scale (then oscale = that scale)
                  float* dw_w = nullptr;         // dw_w: depth-wise 3x3 weights [9][C] fp32 (YOLO11)
                  void* bneck = nullptr; };      // on a bottleneck's cv1: register-fragment weights of the fused cv1+cv2 kernel (bneck64.hip)
 
@@ -120,8 +121,9 @@ struct Reader {
 };
 
 // CYW2: the execution plan travels in the file (caesar_yolo_amd/weights.py:write_cyw2, yolo11_graph.py)
-int parse_plan_v2(cy_ctx* c, Reader& r, Plan* plan, uint32_t* nconv_out, std::vector<std::string>* names) {
-    if (r.u32() != 2) return fail(c, CY_ERR_IO, "unsupported CYW2 version");
+int parse_plan_v2(cy_ctx* c, Reader& r, Plan* plan, uint32_t* nconv_out, std::vector<std::string>* names, uint32_t* version) {
+    *version = r.u32();                                   // 3: conv headers carry a flags word (bit 0: a per-channel scale vector follows the bias)
+    if (*version != 2 && *version != 3) return fail(c, CY_ERR_IO, "unsupported CYW2 version");
     if (r.o + 12 > r.n) return fail(c, CY_ERR_IO, "truncated weight file");
     plan->arch = std::string((const char*)r.p + r.o, strnlen((const char*)r.p + r.o, 8)); r.o += 8;
     plan->scale = (char)r.p[r.o]; r.o += 4;
@@ -230,15 +232,19 @@ int upload_weights(cy_ctx* c, const void* buf, size_t nbytes) {
     const bool v2 = memcmp(buf, "CYW2", 4) == 0;
     r.o = 4;
     Plan plan;
-    uint32_t nc = 0, nconv = 0;
+    uint32_t nc = 0, nconv = 0, fver = 0;
     std::vector<std::string> names;
+    bool has_flags = false;                                  // CYW1 version 2 / CYW2 version 3: a flags word per conv header
     if (v2) {
         plan.ok = false;
-        int rc = parse_plan_v2(c, r, &plan, &nconv, &names);
+        int rc = parse_plan_v2(c, r, &plan, &nconv, &names, &fver);
         if (rc) return rc;
         nc = (uint32_t)plan.nc;
+        has_flags = fver == 3;
     } else {
-        if (r.u32() != 1) return fail(c, CY_ERR_IO, "unsupported CYW version");
+        fver = r.u32();
+        if (fver != 1 && fver != 2) return fail(c, CY_ERR_IO, "unsupported CYW version");
+        has_flags = fver == 2;
         const char scale = (char)r.p[r.o]; r.o += 4;
         nc = r.u32(); nconv = r.u32();
         const uint32_t nnames = r.u32();
@@ -257,6 +263,7 @@ int upload_weights(cy_ctx* c, const void* buf, size_t nbytes) {
     for (uint32_t i = 0; i < nconv; ++i) {
         const uint32_t co = r.u32(), ci = r.u32(), k = r.u32(), s = r.u32(), act = r.u32();
         const uint32_t groups = v2 ? r.u32() : 1u;
+        const uint32_t flags = has_flags ? r.u32() : 0u;
         const uint32_t nl = r.u32();
         const std::string name = r.str(nl);
         if (r.bad) return fail(c, CY_ERR_IO, "truncated weight file");
@@ -272,6 +279,8 @@ int upload_weights(cy_ctx* c, const void* buf, size_t nbytes) {
         }
         const float* W = r.f32((size_t)co * (ci / groups) * k * k);
         const float* b = r.f32(co);
+        // flags bit 0: scale[cout] with W[n] = fl32(w16[n] * scale[n]), w16 the checkpoint's fp16 filter (weights.py: fold(with_scale=True))
+        const float* wscale = (flags & 1u) ? r.f32(co) : nullptr;
         if (r.bad) return fail(c, CY_ERR_IO, "truncated weight file");
         Wsrc[i] = W;
         DevConv& dc = c->dconv[i];
@@ -307,17 +316,19 @@ int upload_weights(cy_ctx* c, const void* buf, size_t nbytes) {
         if (ci % 8) return fail(c, CY_ERR_UNSUPPORTED, "conv input channels must be a multiple of 8: " + name);
         if (c->prec == PREC_F16X3) {
             std::vector<float> osc(cp);
-            dc.wbytes = packed_weight_bytes_x3(co, ci, k);
+            // two passes when the filter is exactly an fp16 filter times a per-channel scale (CY_X3_PASSES=3 forces the general form)
+            dc.passes = env_knob("CY_X3_PASSES", 0) == 3 ? 3 : x3_passes(W, (int)co, (int)ci, (int)k, wscale);
+            dc.wbytes = packed_weight_bytes_x3(co, ci, k, 128, dc.passes);
             packed.resize(dc.wbytes);
-            pack_weights_x3(W, co, ci, k, packed.data(), osc.data());
+            pack_weights_x3(W, co, ci, k, packed.data(), osc.data(), 128, dc.passes, wscale);
             HIPCHK(c, hipMalloc(&dc.w, dc.wbytes));
             HIPCHK(c, hipMemcpy(dc.w, packed.data(), dc.wbytes, hipMemcpyHostToDevice));
             HIPCHK(c, hipMalloc(&dc.oscale, 4 * cp));
             HIPCHK(c, hipMemcpy(dc.oscale, osc.data(), 4 * cp, hipMemcpyHostToDevice));
             if (k == 3 && s == 1 && ci % 64 == 0) {          // second copy with 64-byte K chunks (conv3x3_wide_kernel)
-                dc.w32bytes = packed_weight_bytes_x3(co, ci, k, 64);
+                dc.w32bytes = packed_weight_bytes_x3(co, ci, k, 64, dc.passes);
                 packed.resize(dc.w32bytes);
-                pack_weights_x3(W, co, ci, k, packed.data(), osc.data(), 64);
+                pack_weights_x3(W, co, ci, k, packed.data(), osc.data(), 64, dc.passes, wscale);
                 HIPCHK(c, hipMalloc(&dc.w32, dc.w32bytes));
                 HIPCHK(c, hipMemcpy(dc.w32, packed.data(), dc.w32bytes, hipMemcpyHostToDevice));
             }
@@ -464,6 +475,13 @@ int cy_load_weights(cy_ctx* c, const char* path) {
 }
 
 int cy_num_classes(const cy_ctx* c) { return c && c->loaded ? c->plan.nc : -1; }
+int cy_weight_passes(const cy_ctx* c, int* out2) {
+    if (!c || !c->loaded || !out2) return CY_ERR_ARG;
+    out2[0] = out2[1] = 0;
+    if (c->prec == PREC_F16X3)
+        for (const auto& d : c->dconv) if (d.oscale) out2[d.passes == 2 ? 0 : 1] += 1;
+    return CY_OK;
+}
 const char* cy_class_name(const cy_ctx* c, int i) {
     if (!c || !c->loaded || i < 0 || i >= (int)c->names.size()) return nullptr;
     return c->names[i].c_str();
@@ -731,7 +749,7 @@ static int forward_on(cy_ctx* c, const void* d_netin, int B, int H, int W, float
             };
             a.in0 = tp(o.in0); a.in0_ct = cm * t0.C; a.in0_coff = o.in0_coff; a.c0 = o.c0; a.up0 = o.up0;
             a.in0_bytes = span(o.in0);
-            a.split = x3; a.in0_lo = t0.C; a.oscale = c->dconv[o.conv].oscale;
+            a.split = x3 ? c->dconv[o.conv].passes : 0; a.in0_lo = t0.C; a.oscale = c->dconv[o.conv].oscale;
             int lev_in = o.up0 ? t0.level - 1 : t0.level;
             if (o.in1 >= 0) {
                 const Tensor& t1 = p.tensors[o.in1];
@@ -866,11 +884,12 @@ int cy_conv_bn_silu(cy_ctx* c, const void* d_in, int B, int Hi, int Wi, int Cin,
         hipStream_t st = (hipStream_t)stream;
         const int pad = k / 2, Ho = (Hi + 2 * pad - k) / s + 1, Wo = (Wi + 2 * pad - k) / s + 1, cp = (Cout + 127) / 128 * 128;
         const size_t nin = (size_t)B * Hi * Wi, nout = (size_t)B * Ho * Wo;
-        const size_t wb = packed_weight_bytes_x3(Cout, Cin, k), wb32 = (k == 3 && s == 1 && Cin % 64 == 0) ? packed_weight_bytes_x3(Cout, Cin, k, 64) : 0;
+        const int passes = env_knob("CY_X3_PASSES", 0) == 3 ? 3 : x3_passes(h_w, Cout, Cin, k, nullptr);     // 2 when every weight is an fp16 value
+        const size_t wb = packed_weight_bytes_x3(Cout, Cin, k, 128, passes), wb32 = (k == 3 && s == 1 && Cin % 64 == 0) ? packed_weight_bytes_x3(Cout, Cin, k, 64, passes) : 0;
         std::vector<char> packed(wb), p32(wb32);
         std::vector<float> osc(cp), bias(cp, 0.0f);
-        pack_weights_x3(h_w, Cout, Cin, k, packed.data(), osc.data());
-        if (wb32) pack_weights_x3(h_w, Cout, Cin, k, p32.data(), osc.data(), 64);
+        pack_weights_x3(h_w, Cout, Cin, k, packed.data(), osc.data(), 128, passes);
+        if (wb32) pack_weights_x3(h_w, Cout, Cin, k, p32.data(), osc.data(), 64, passes);
         memcpy(bias.data(), h_b, 4 * Cout);
         void *dw = nullptr, *dw32 = nullptr, *xin = nullptr, *xres = nullptr, *xout = nullptr; float *db = nullptr, *dsc = nullptr;
         auto cleanup = [&]() { for (void* q : {dw, dw32, xin, xres, xout, (void*)db, (void*)dsc}) if (q) hipFree(q); };
@@ -890,7 +909,7 @@ int cy_conv_bn_silu(cy_ctx* c, const void* d_in, int B, int Hi, int Wi, int Cin,
         if (e == hipSuccess) {
             ConvArgs a{};
             a.in0 = xin; a.in0_ct = 2 * Cin; a.c0 = Cin; a.in0_bytes = (uint32_t)(nin * Cin * 4); a.in0_lo = Cin;
-            a.wgt = dw; a.wgt_bytes = (uint32_t)wb; a.bias = db; a.wgt32 = dw32; a.wgt32_bytes = (uint32_t)wb32; a.oscale = dsc; a.split = 1;
+            a.wgt = dw; a.wgt_bytes = (uint32_t)wb; a.bias = db; a.wgt32 = dw32; a.wgt32_bytes = (uint32_t)wb32; a.oscale = dsc; a.split = passes;
             a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ho = Ho; a.Wo = Wo; a.Cin = Cin; a.Cout = Cout; a.k = k; a.s = s; a.act = act;
             a.out = xout; a.out_ct = 2 * Cout; a.out_lo = Cout; a.out_bs = Ho * Wo;
             if (d_res) { a.res = xres; a.res_ct = 2 * Cout; a.res_lo = Cout; }
@@ -1131,6 +1150,12 @@ int cy_detect_tiles(cy_ctx* c, const float* d_mosaic, int MH, int MW, const int*
     const int sl = small ? 2 : (int)(c->batches & 1);
     const bool reuse = small ? c->small_batches >= 1 : c->batches >= 2;
     hipStream_t sf = small ? c->s_small : sm;
+    // CY_SIDE_STREAMS=1 (read per call; TileEngine sets it when a process group exists): post-processing shares the preprocessing
+    // stream, so a context owns THREE streams besides the caller's (side, second forward) and a collective library's own stream
+    // (RCCL: one per communicator) still finds a hardware queue of its own -- the HIP runtime maps streams onto four queues, and two
+    // busy streams on one queue serialise.  Both side jobs are short and latency-bound; in one stream they
+    // only wait for each other.
+    hipStream_t spost = env_knob("CY_SIDE_STREAMS", 2) == 1 ? c->s_pre : c->s_post;
     c->slot = sl;
     // order the side streams after whatever the caller already queued on `stream` -- only where that matters: the first batch
     // after load / flush, or after cy_mosaic_prepare.  Later batches are ordered by ev_fwd / ev_post alone, so that the
@@ -1159,11 +1184,11 @@ int cy_detect_tiles(cy_ctx* c, const float* d_mosaic, int MH, int MW, const int*
     }
     if (rc) { c->slot = 0; return rc; }
     HIPCHK(c, hipEventRecord(c->ev_fwd[sl], sf));
-    HIPCHK(c, hipStreamWaitEvent(c->s_post, c->ev_fwd[sl], 0));
-    rc = cy_decode_nms(c, c->S().pred, B, lb.H, lb.W, th, tw, conf, iou, c->S().det, c->S().det_anchor, c->S().det_count, c->s_post);
-    if (!rc) rc = cy_iou_merge(c, c->S().det, c->S().det_count, B, conf, soft, hard, d_out, d_out_count, nullptr, c->s_post);
+    HIPCHK(c, hipStreamWaitEvent(spost, c->ev_fwd[sl], 0));
+    rc = cy_decode_nms(c, c->S().pred, B, lb.H, lb.W, th, tw, conf, iou, c->S().det, c->S().det_anchor, c->S().det_count, spost);
+    if (!rc) rc = cy_iou_merge(c, c->S().det, c->S().det_count, B, conf, soft, hard, d_out, d_out_count, nullptr, spost);
     if (rc) { c->slot = 0; return rc; }
-    HIPCHK(c, hipEventRecord(c->ev_post[sl], c->s_post));
+    HIPCHK(c, hipEventRecord(c->ev_post[sl], spost));
     if (small) c->small_batches++; else c->batches++;
     c->slot = 0;
     return CY_OK;

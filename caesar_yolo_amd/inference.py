@@ -209,6 +209,14 @@ class TileEngine(object):
         self.tid_all = torch.tensor(order if order else [0], dtype=torch.float32, device=dev)
         self.n_my = n_my
         self.gathered = None
+        # stream budget: with a process group in the process the collective library owns a stream too; the
+        # context then keeps preprocessing and post-processing on ONE side stream (caller + side + second forward + RCCL = 4 queues)
+        try:
+            import torch.distributed as dist
+            if world > 1 or (dist.is_available() and dist.is_initialized()):
+                os.environ.setdefault("CY_SIDE_STREAMS", "1")
+        except Exception:
+            pass
 
     def origin_of(self, img):
         """(x, y) of the mosaic pixel at [0, 0] of a device image of the launch plan (regions are rebased)."""
@@ -234,9 +242,12 @@ class TileEngine(object):
         return n
 
     def gather(self):
-        """ONE collective: all-gather of the fixed-capacity record buffers (RCCL over xGMI when world > 1)."""
-        if self.world > 1:
-            import torch.distributed as dist
+        """ONE collective: all-gather of the fixed-capacity record buffers (RCCL over xGMI when world > 1).  The records are complete
+        on the caller's stream before it is issued: run_local() ends with flush() (the stream waits for the post-processing events of
+        the last batches) and fills `rec` with ordinary stream-ordered copies; the process group orders its own stream behind ours.
+        With a process group of ONE rank (bench.py CY_BENCH_FORCE_DIST=1, tests/test_gpu_multirank.py) the collective still runs."""
+        import torch.distributed as dist
+        if self.world > 1 or (dist.is_available() and dist.is_initialized()):
             out = torch.empty((self.world,) + tuple(self.rec.shape), dtype=self.rec.dtype, device=self.rec.device)
             if dist.get_backend() == "gloo":          # CPU rehearsal of the same collective (tests, 1-GPU boxes)
                 mine = self.rec.cpu()

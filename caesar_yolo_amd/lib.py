@@ -16,7 +16,7 @@ PRECISIONS = {"fp16": F16, "f16": F16, "half": F16, "fp32": F32, "f32": F32, "fl
 
 EXPORTS = [
     "cy_create", "cy_destroy", "cy_last_error", "cy_load_weights", "cy_load_weights_mem", "cy_num_classes",
-    "cy_class_name", "cy_plan_num_convs", "cy_plan_conv_desc", "cy_letterbox_geometry", "cy_num_anchors",
+    "cy_weight_passes", "cy_class_name", "cy_plan_num_convs", "cy_plan_conv_desc", "cy_letterbox_geometry", "cy_num_anchors",
     "cy_pred_elems", "cy_profile_enable", "cy_profile_summary", "cy_profile_summary_lane", "cy_profile_layers", "cy_mosaic_prepare", "cy_letterbox_pack", "cy_preproc", "cy_preproc_planes", "cy_preproc_params", "cy_forward", "cy_debug_read_conv",
     "cy_decode_nms", "cy_debug_stamps", "cy_debug_cand_counts", "cy_iou_merge", "cy_detect_tiles", "cy_detect_flush", "cy_detect_fence", "cy_compact_records", "cy_detect_counters", "cy_conv_bn_silu", "cy_bottleneck64", "cy_make_tile_records",
     "cy_merge_edge_sources",
@@ -81,6 +81,7 @@ def load():
         "cy_load_weights": (C.c_int, [vp, C.c_char_p]),
         "cy_load_weights_mem": (C.c_int, [vp, vp, C.c_size_t]),
         "cy_num_classes": (C.c_int, [vp]),
+        "cy_weight_passes": (C.c_int, [vp, ip]),
         "cy_class_name": (C.c_char_p, [vp, C.c_int]),
         "cy_plan_num_convs": (C.c_int, [C.c_char, C.c_int]),
         "cy_plan_conv_desc": (C.c_int, [C.c_char, C.c_int, C.c_int, C.POINTER(cy_conv_desc)]),

@@ -205,6 +205,12 @@ class HipDetector(object):
         self._chk(self.lib.cy_forward(self.ctx, self._p(netin), B, H, Wd, self._p(pred), self._stream()))
         return pred
 
+    def weight_passes(self):
+        """fp16x3 context: (convolutions on the two-pass form, on the three-pass form); (0, 0) in the other contexts."""
+        out = (C.c_int * 2)()
+        self._chk(self.lib.cy_weight_passes(self.ctx, out))
+        return int(out[0]), int(out[1])
+
     def profile(self, on):
         self._chk(self.lib.cy_profile_enable(self.ctx, int(on)))            # True/1: every forward call; N > 1: every N-th
 
@@ -352,6 +358,19 @@ class YOLO(object):
             if not os.path.exists(path):
                 tmp = path + ".%d.tmp" % os.getpid()
                 W.make_seeded_file(tmp, scale, nc, seed)
+                os.replace(tmp, path)
+            return path
+        if isinstance(weights, str) and weights.startswith("seeded11:"):           # seeded YOLO11: "seeded11:<scale>:<nc>[:seed]"
+            parts = weights.split(":")
+            scale, nc = parts[1], int(parts[2])
+            seed = int(parts[3]) if len(parts) > 3 else 11
+            import tempfile
+            cache = os.environ.get("CAESAR_YOLO_CACHE", os.path.join(tempfile.gettempdir(), "caesar_yolo_amd_%d" % os.getuid()))
+            os.makedirs(cache, exist_ok=True)
+            path = os.path.join(cache, "seeded11_%s_nc%d_%d.cyw" % (scale, nc, seed))
+            if not os.path.exists(path):
+                tmp = path + ".%d.tmp" % os.getpid()
+                W.make_seeded11_file(tmp, scale, nc, seed)
                 os.replace(tmp, path)
             return path
         if not os.path.isfile(weights):

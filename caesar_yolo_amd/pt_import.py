@@ -319,7 +319,7 @@ def convert_pt_to_cyw(pt_path, cyw_path):
     if r["arch"] == "yolo11":
         from . import yolo11_graph as G
         g = G.build(r["scale"], r["nc"])
-        W.write_cyw2(cyw_path, g, W.fold_graph(r["sd"], g), r["names"])
+        W.write_cyw2(cyw_path, g, W.fold_graph(r["sd"], g, with_scale=True), r["names"])
     else:
-        W.write_cyw(cyw_path, W.fold(r["sd"], r["scale"], r["nc"]), r["names"], r["scale"])
+        W.write_cyw(cyw_path, W.fold(r["sd"], r["scale"], r["nc"], with_scale=True), r["names"], r["scale"])
     return r["scale"], r["names"]

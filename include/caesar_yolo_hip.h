@@ -76,6 +76,10 @@ int cy_load_weights(cy_ctx* ctx, const char* path);                 /* CYW1 file
 int cy_load_weights_mem(cy_ctx* ctx, const void* buf, size_t nbytes);
 int cy_num_classes(const cy_ctx* ctx);                               /* len(model.names), caesar_yolo/evaluation.py:46-47 */
 const char* cy_class_name(const cy_ctx* ctx, int i);
+/* fp16x3 context: how many convolutions run the two-pass form (filter = fp16 values x a per-channel scale, exactly: what a
+ * checkpoint stored in fp16 and folded with its BatchNorm in fp32 is -- ultralytics' own load path) and how
+ * many the general three-pass form.  out2[0] = two-pass layers, out2[1] = three-pass layers (both 0 in the other contexts). */
+int cy_weight_passes(const cy_ctx* ctx, int* out2);
 
 /* ---- host-only helpers (no GPU needed) ------------------------------------------------------- */
 int cy_plan_num_convs(char scale, int nc);

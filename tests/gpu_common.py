@@ -43,3 +43,26 @@ def netin_from_chw(x_bchw, dtype):
     t = torch.zeros((b, h, w, 4), dtype=torch.float32)
     t[..., :3] = x_bchw.permute(0, 2, 3, 1)
     return t.to(dtype).cuda()
+
+
+def assert_same_detections(got_b, got_s, got_c, ref_b, ref_s, ref_c, box_tol=5e-3, score_tol=2e-5, what=""):
+    """Detections in the oracle's order, except that rows whose scores lie within `score_tol` of each other may come in either
+    order (a score tie is decided by the last bit of a 100-layer sum: either arithmetic may win it).  Every row must find its
+    partner -- same class, score within score_tol, box within box_tol (pixels) -- inside its tie group.  Returns the number of
+    rows found at another position than the oracle's (printed by the callers)."""
+    got_b, got_s, got_c = np.asarray(got_b, np.float64).reshape(-1, 4), np.asarray(got_s, np.float64), np.asarray(got_c).astype(int)
+    ref_b, ref_s, ref_c = np.asarray(ref_b, np.float64).reshape(-1, 4), np.asarray(ref_s, np.float64), np.asarray(ref_c).astype(int)
+    assert len(got_s) == len(ref_s), "%s: %d detections, the oracle has %d" % (what, len(got_s), len(ref_s))
+    used, moved = np.zeros(len(ref_s), bool), 0
+    for i in range(len(got_s)):
+        cand = [i] + [j for j in range(len(ref_s)) if j != i and abs(ref_s[j] - got_s[i]) <= score_tol]
+        for j in cand:
+            if j < len(ref_s) and not used[j] and got_c[i] == ref_c[j] and abs(got_s[i] - ref_s[j]) <= score_tol \
+                    and np.abs(got_b[i] - ref_b[j]).max() <= box_tol:
+                used[j] = True
+                moved += int(j != i)
+                break
+        else:
+            raise AssertionError("%s: detection %d (class %d, score %.7f, box %s) has no partner within the tolerances; oracle row %d: "
+                                 "class %d, score %.7f, box %s" % (what, i, got_c[i], got_s[i], got_b[i], i, ref_c[i], ref_s[i], ref_b[i]))
+    return moved

@@ -7,7 +7,7 @@ import json
 import os
 import numpy as np
 import pytest
-from gpu_common import seeded_weights, oracle_model, ROOT
+from gpu_common import seeded_weights, oracle_model, assert_same_detections, ROOT
 
 pytestmark = pytest.mark.gpu
 CONF, IOU, SOFT, HARD = 0.7, 0.5, 0.3, 0.8
@@ -42,9 +42,9 @@ def test_model_call_with_the_reference_keyword_set(caplog):
     det, _, _, _ = oracle_model().predict_raw(cube, 640, CONF, IOU)
     b, s, c = got[0]
     assert b.dtype == np.float32 and b.shape == (len(s), 4) and len(s) == det.shape[0] and len(s) > 0
-    np.testing.assert_allclose(s, det[:, 4].numpy(), atol=2e-5)          # measured: <= 7e-6
-    np.testing.assert_array_equal(c.astype(int), det[:, 5].numpy().astype(int))
-    np.testing.assert_allclose(b, det[:, :4].numpy(), atol=5e-3)        # pixels; measured: <= 2.1e-3
+    # scores 2e-5 (measured <= 7e-6), boxes 5e-3 px (measured <= 2.1e-3), classes equal; rows inside a score tie may swap
+    moved = assert_same_detections(b, s, c, det[:, :4].numpy(), det[:, 4].numpy(), det[:, 5].numpy(), 5e-3, 2e-5, "model call")
+    print("model call, reference keyword set: %d boxes, %d inside score ties at another position" % (len(s), moved))
     assert (np.diff(s) <= 0).all() and b.min() >= 0 and b.max() <= 132          # conf-descending, clipped to the image
 
 
@@ -161,9 +161,7 @@ def test_analyzer_predict_three_channel_array():
             det, _, _, _ = oracle_model().predict_raw(ref_img, 256, 0.05, IOU)        # (a cube of unrelated channels scores low on the seeded weights)
             kb, ks, kc, _ = R.process_detections(det[:, :4].numpy(), det[:, 4].numpy(), det[:, 5].numpy(), 0.05, SOFT, HARD)
             assert len(an.scores_final) == len(ks) and len(ks) >= 3
-            np.testing.assert_allclose(np.array(an.scores_final), ks, atol=2e-5)
-            np.testing.assert_array_equal(np.array(an.class_ids_final), np.asarray(kc).astype(int))
-            np.testing.assert_allclose(np.array(an.bboxes_final), kb, atol=5e-3)
+            assert_same_detections(an.bboxes_final, an.scores_final, an.class_ids_final, kb, ks, kc, 5e-3, 2e-5, "Analyzer " + prec)
         flat = cube_in.copy()
         flat[:2] = 0.0                                            # rows 0 and 1 all zero in every channel -> constant rows
         assert Analyzer(model, c).predict(flat, image_id="flat") == -1

@@ -106,10 +106,12 @@ def test_two_group_and_ring_kernels_are_repeatable(case):
         assert torch.equal(first, det.conv_bn_silu(xd, w1, b, 1, 1, True, rd))
 
 
+@pytest.mark.parametrize("w16", [False, True])
 @pytest.mark.parametrize("seed", list(range(24)))
-def test_conv_random_geometry_fp16x3(seed):
+def test_conv_random_geometry_fp16x3(seed, w16):
     """The same seeded random geometries through the fp16x3 context (three-pass K walk of the wide / pixels-direct / generic
-    kernels, scaled weights, high / low output halves) against F.conv2d in float64: 4e-6 of the output scale."""
+    kernels, scaled weights, high / low output halves) against F.conv2d in float64: 4e-6 of the output scale.
+    w16: the weights are fp16 values (what an ultralytics checkpoint stores) -> the TWO-pass form [x_lo w | x_hi w] of every kernel."""
     rng = np.random.default_rng(1000 + seed)
     k = int(rng.choice([1, 3]))
     s = int(rng.choice([1, 2])) if k == 3 else 1
@@ -126,6 +128,8 @@ def test_conv_random_geometry_fp16x3(seed):
     w = torch.randn((Cout, Cin, k, k), generator=g) / (Cin * k * k) ** 0.5
     w[0] *= 1e-3                                          # rows of very different magnitude: the per-channel weight scale
     w[-1] *= 50.0
+    if w16:
+        w = w.half().float()                              # (row 0 then holds fp16 subnormals: exact in the MFMA)
     b = torch.randn((Cout,), generator=g) * 0.1
     y = F.conv2d(x.double(), w.double(), b.double(), stride=s, padding=k // 2)
     if act:
@@ -142,7 +146,7 @@ def test_conv_random_geometry_fp16x3(seed):
     assert got.shape == y.shape
     scale = max(float(y.abs().max()), 1.0)
     err = float((got - y).abs().max())
-    print("fp16x3 B%d %dx%d %d->%d k%d s%d: max abs err %.3e of scale %.2f (%.2e)" % (B, H, Wd, Cin, Cout, k, s, err, scale, err / scale))
+    print("fp16x3%s B%d %dx%d %d->%d k%d s%d: max abs err %.3e of scale %.2f (%.2e)" % (" two-pass" if w16 else "", B, H, Wd, Cin, Cout, k, s, err, scale, err / scale))
     assert err <= 4e-6 * scale, "B%d %dx%d %d->%d k%d s%d act%d res%d: max abs err %.3e (scale %.2f)" % (
         B, H, Wd, Cin, Cout, k, s, act, use_res, err, scale)
 
@@ -308,10 +312,11 @@ def test_strip_form_of_the_wide_kernel(case, monkeypatch):
         assert torch.equal(out, det.conv_bn_silu(xd, w.numpy(), b.numpy(), 3, 1, True, rd))
 
 
+@pytest.mark.parametrize("w16", [False, True])
 @pytest.mark.parametrize("case", [(5, 80, 80, 128, 128, True), (7, 40, 40, 256, 256, False), (9, 20, 20, 512, 256, True), (3, 52, 64, 128, 128, True),
                                   (2, 33, 47, 64, 192, True), (2, 100, 126, 64, 128, False), (40, 64, 64, 128, 128, True), (3, 32, 64, 256, 256, False),
                                   (37, 8, 8, 256, 256, True), (70, 4, 4, 512, 256, False), (9, 6, 10, 128, 192, True), (70, 4, 4, 512, 64, False)])
-def test_fp16x3_persistent_and_strip_forms(case, monkeypatch):
+def test_fp16x3_persistent_and_strip_forms(case, w16, monkeypatch):
     """fp16x3 context: the strip form of the persistent wide kernel (three-pass K walk over the flattened batch, scaled / split epilogue,
     residual as high + low halves requested two fragments at a time) and, with CY_X3_PERSIST=1, its 2-D form -- against F.conv2d in
     float64 (4e-6 of the output scale) and bit-identical to the one-patch fp16x3 wide kernel where that one applies."""
@@ -320,6 +325,8 @@ def test_fp16x3_persistent_and_strip_forms(case, monkeypatch):
     g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
     x = torch.randn((B, Cin, H, W), generator=g)
     w = torch.randn((Cout, Cin, 3, 3), generator=g) / (Cin * 9) ** 0.5
+    if w16:
+        w = w.half().float()                  # fp16-exact filter: the two-pass form of the same kernels
     b = torch.randn((Cout,), generator=g) * 0.1
     y = F.silu(F.conv2d(x.double(), w.double(), b.double(), padding=1))
     res = torch.randn(y.shape, generator=g) if use_res else None

@@ -12,7 +12,7 @@ import os
 import numpy as np
 import pytest
 import torch
-from gpu_common import detector, oracle_model, netin_from_chw, ROOT
+from gpu_common import detector, oracle_model, netin_from_chw, assert_same_detections, ROOT
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -110,13 +110,17 @@ def test_model_call_end_to_end_fp32(name, imgsz, conf, prec):
     near = int(np.sum(np.abs(sc - conf) < 1e-5))
     if near == 0:
         assert len(cf) == d_ref.shape[0]
-        assert np.array_equal(cl, d_ref[:, 5].numpy())
         H, W = [s * 8 for s in m.net.level_shapes[0]]
-        berr = float(np.abs(xyxy - d_ref[:, :4].numpy()).max()) if len(cf) else 0.0
-        serr = float(np.abs(cf - d_ref[:, 4].numpy()).max()) if len(cf) else 0.0
-        print("end-to-end %s %s@%d: %d boxes, max |dbox| = %.3e px (%.2e normalised), max |dscore| = %.3e"
-              % (prec, name, imgsz, len(cf), berr, berr / max(H, W), serr))
-        assert berr <= E2E_BOX_PX * max(1.0, imgsz / 640.0)      # (coordinates of a 1024-px network input carry 1.6x the fp32 ulp)
-        assert serr <= E2E_SCORE
+        btol = E2E_BOX_PX * max(1.0, imgsz / 640.0)              # (coordinates of a 1024-px network input carry 1.6x the fp32 ulp)
+        moved = assert_same_detections(xyxy, cf, cl, d_ref[:, :4].numpy(), d_ref[:, 4].numpy(), d_ref[:, 5].numpy(), btol, E2E_SCORE,
+                                       "%s %s@%d" % (prec, name, imgsz))
+        if moved == 0:
+            berr = float(np.abs(xyxy - d_ref[:, :4].numpy()).max()) if len(cf) else 0.0
+            serr = float(np.abs(cf - d_ref[:, 4].numpy()).max()) if len(cf) else 0.0
+            print("end-to-end %s %s@%d: %d boxes, max |dbox| = %.3e px (%.2e normalised), max |dscore| = %.3e"
+                  % (prec, name, imgsz, len(cf), berr, berr / max(H, W), serr))
+        else:
+            print("end-to-end %s %s@%d: %d boxes within %.1e px / %.1e, %d of them at another position inside a score tie"
+                  % (prec, name, imgsz, len(cf), btol, E2E_SCORE, moved))
     else:
         pytest.skip("%d candidates within 1e-5 of the confidence threshold" % near)

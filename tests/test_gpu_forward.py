@@ -185,6 +185,31 @@ def test_fp16x3_results_do_not_depend_on_the_batch():
         assert torch.equal(p1[0], p4[i]), "tile %d differs between batch 1 and batch 4" % i
 
 
+def test_fp16x3_two_pass_form_on_fp16_checkpoints(monkeypatch):
+    """fp16x3 context, round 4: a checkpoint whose tensors are fp16 values (what ultralytics stores; the seeded checkpoints are
+    written that way) gives folded filters that are EXACTLY an fp16 filter times the BatchNorm factor of their channel; the
+    packer recognises it from the numbers (x3_passes) and every MFMA layer runs two passes [x_lo w | x_hi w] with the factor in the
+    epilogue instead of three.  Both forms against the oracle (2e-4), and against each other."""
+    from gpu_common import seeded_weights
+    from caesar_yolo_amd.model import HipDetector
+    det2 = detector("fp16x3")
+    n2, n3 = det2.weight_passes()
+    assert (n2, n3) == (102, 0), "seeded yolov8l: all 102 MFMA convolutions on the two-pass form, got %d / %d" % (n2, n3)
+    monkeypatch.setenv("CY_X3_PASSES", "3")
+    det3 = HipDetector(seeded_weights()[0], device=0, precision="fp16x3", max_batch=4, max_imgsz=640)
+    monkeypatch.delenv("CY_X3_PASSES")
+    assert det3.weight_passes() == (0, 102)
+    base = _tile("big512", 256, 256)
+    x, raw, _ = _oracle_forward([base, base[::-1].copy()], 256)
+    xin = netin_from_chw(x, det2.dtype)
+    p2, p3 = det2.forward(xin).cpu(), det3.forward(xin).cpu()
+    det3.close()
+    sc = max(1.0, float(raw.abs().max()))
+    e2, e3, e23 = float((p2 - raw).abs().max()), float((p3 - raw).abs().max()), float((p2 - p3).abs().max())
+    print("fp16x3 raw head output vs oracle: two-pass %.3e, three-pass %.3e, between them %.3e (scale %.2f)" % (e2, e3, e23, sc))
+    assert e2 <= 2e-4 * sc and e3 <= 2e-4 * sc
+
+
 @pytest.mark.parametrize("shape", [(3, 160, 192), (20, 256, 256), (1, 512, 512), (5, 96, 416)])
 def test_two_group_stem_kernel_is_bit_identical(shape, monkeypatch):
     """The persistent two-group form of the fused stem + first down conv (CY_STEM_V=2: 8 x 16 output patches, one wave group

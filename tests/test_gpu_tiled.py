@@ -11,7 +11,7 @@ import os
 import numpy as np
 import pytest
 import torch
-from gpu_common import seeded_weights, oracle_model, ROOT
+from gpu_common import seeded_weights, oracle_model, assert_same_detections, ROOT
 
 pytestmark = pytest.mark.gpu
 CONF, IOU, SOFT, HARD = 0.7, 0.5, 0.3, 0.8
@@ -142,9 +142,8 @@ def test_predict_tiles_batched_entry():
         assert len(r.boxes.conf) == len(ks)
         ndet += len(ks)
         if len(ks):
-            np.testing.assert_allclose(r.boxes.conf.cpu().numpy(), ks, atol=2e-5)
-            np.testing.assert_array_equal(r.boxes.cls.cpu().numpy().astype(int), np.asarray(kc).astype(int))
-            np.testing.assert_allclose(r.boxes.xyxy.cpu().numpy(), kb, atol=5e-3)       # pixels
+            assert_same_detections(r.boxes.xyxy.cpu().numpy(), r.boxes.conf.cpu().numpy(), r.boxes.cls.cpu().numpy(), kb, ks, kc,
+                                   5e-3, 2e-5, "tile (%d, %d)" % (x0, y0))          # pixels; scores
     assert ndet >= 8
     with pytest.raises(ValueError):
         model.predict_tiles(mosaic, [(0, 256, 0, 256), (0, 200, 0, 256)], cfg, imgsz=256)

@@ -51,6 +51,30 @@ def test_yolo11_forward_matches_oracle(tmp_path, scale, prec, tol_raw, tol_tap):
     assert err <= tol_raw * max(1.0, float(raw.abs().max())), "raw head output: max abs err %.3e" % err
 
 
+def test_seeded_yolo11_weights_of_the_benchmark():
+    """`YOLO("seeded11:<scale>:<nc>")` (bench.py --weights seeded11:l:5): the product-side seeded YOLO11 weights -- the random draw
+    normalised by the tabulated per-conv factors, fp16-valued like a checkpoint on disk -- load, run every MFMA layer of the fp16x3
+    context on the two-pass form, keep activations O(1) and match the oracle (2e-4)."""
+    from caesar_yolo_amd import weights as W
+    from caesar_yolo_amd.model import YOLO
+    from oracle import yolo11_ref as O
+    g, wd = W.seeded11_folded("n", 5)
+    model = YOLO("seeded11:n:5", precision="fp16x3", max_batch=2, max_imgsz=256, device=0)
+    det = model.engine(0)
+    n2, n3 = det.weight_passes()
+    assert n3 == 0 and n2 > 60, (n2, n3)
+    rng = np.random.default_rng(9)
+    x = torch.from_numpy(rng.uniform(0, 1, (2, 3, 256, 224)).astype(np.float32))
+    with torch.no_grad():
+        raw = O.Net11(wd, "n", 5).forward(x).permute(0, 2, 1).contiguous()
+    pred = det.forward(netin_from_chw(x, det.dtype)).cpu()
+    sc = max(1.0, float(raw.abs().max()))
+    err = float((pred - raw).abs().max())
+    print("seeded11:n:5 fp16x3 raw head output vs oracle: %.3e (scale %.2f; %d two-pass layers)" % (err, sc, n2))
+    assert 1.0 < sc < 100.0 and err <= 2e-4 * sc
+    det.close()
+
+
 def test_yolo11_model_call_end_to_end(tmp_path):
     """The reference-shaped model call (`YOLO(weights)(image, imgsz=, conf=, iou=)`, caesar_yolo/evaluation.py:181-193) with a
     YOLO11 weight file: LetterBox -> network -> decode -> NMS -> scale_boxes on the GPU (f32 context) against the oracle
