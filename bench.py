@@ -29,6 +29,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # before the first HIP call: see caesar_yolo_amd/__init__.py (stream budget)
 sys.path.insert(0, ROOT)
 
 PEAK_FP16_DENSE_TFLOPS = 2500.0      # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md, "~2.5 PF dense")
@@ -303,8 +304,10 @@ def run_rank(args):
     if world > 1 or forced:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         kw = dict(rank=0, world_size=1) if forced else {}
-        if backend == "nccl":
+        if backend == "nccl" and os.environ.get("CY_BENCH_LAZY_PG") != "1":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local), **kw)
+        elif backend == "nccl":                # (experiment: the communicator and its stream are created by the first collective)
+            dist.init_process_group("nccl", **kw)
         else:
             dist.init_process_group(backend, **kw)
     if rank == 0:

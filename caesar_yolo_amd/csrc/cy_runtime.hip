@@ -1150,12 +1150,17 @@ int cy_detect_tiles(cy_ctx* c, const float* d_mosaic, int MH, int MW, const int*
     const int sl = small ? 2 : (int)(c->batches & 1);
     const bool reuse = small ? c->small_batches >= 1 : c->batches >= 2;
     hipStream_t sf = small ? c->s_small : sm;
-    // CY_SIDE_STREAMS=1 (read per call; TileEngine sets it when a process group exists): post-processing shares the preprocessing
-    // stream, so a context owns THREE streams besides the caller's (side, second forward) and a collective library's own stream
-    // (RCCL: one per communicator) still finds a hardware queue of its own -- the HIP runtime maps streams onto four queues, and two
-    // busy streams on one queue serialise.  Both side jobs are short and latency-bound; in one stream they
-    // only wait for each other.
-    hipStream_t spost = env_knob("CY_SIDE_STREAMS", 2) == 1 ? c->s_pre : c->s_post;
+    // Stream budget.  The HIP runtime maps streams onto four hardware queues; two BUSY streams on one queue serialise (DESIGN.md
+    // section 5).  A context owns four: the caller's, preprocessing, post-processing and the second forward stream (small-batch lane /
+    // second half of a split batch).  A collective library in the process (RCCL: one stream per communicator) is a fifth, and even idle
+    // it displaces one of ours onto a shared queue: measured at N = 1 with a one-rank RCCL group, 176.7 -> 187.7 ms per pass.
+    // CY_SIDE_STREAMS (read per call; TileEngine sets 3 when a process group exists): 2 = four streams (default); 1 = post-processing
+    // shares the preprocessing stream (the NMS of batch i-1 then delays the statistics of batch i+1: 191.7 ms); 3 = post-processing
+    // shares the SECOND FORWARD stream (decode / NMS / merge are ~1 ms per batch next to a small-batch forward that runs beside the
+    // main lane anyway), i.e. three streams + the library's = four queues.
+    const int side_mode = env_knob("CY_SIDE_STREAMS", 2);
+    if (side_mode == 3) { rc = ensure_side_forward_stream(c); if (rc) return rc; }
+    hipStream_t spost = side_mode == 1 ? c->s_pre : (side_mode == 3 ? c->s_fwd2 : c->s_post);
     c->slot = sl;
     // order the side streams after whatever the caller already queued on `stream` -- only where that matters: the first batch
     // after load / flush, or after cy_mosaic_prepare.  Later batches are ordered by ev_fwd / ev_post alone, so that the

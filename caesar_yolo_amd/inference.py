@@ -209,14 +209,6 @@ class TileEngine(object):
         self.tid_all = torch.tensor(order if order else [0], dtype=torch.float32, device=dev)
         self.n_my = n_my
         self.gathered = None
-        # stream budget: with a process group in the process the collective library owns a stream too; the
-        # context then keeps preprocessing and post-processing on ONE side stream (caller + side + second forward + RCCL = 4 queues)
-        try:
-            import torch.distributed as dist
-            if world > 1 or (dist.is_available() and dist.is_initialized()):
-                os.environ.setdefault("CY_SIDE_STREAMS", "1")
-        except Exception:
-            pass
 
     def origin_of(self, img):
         """(x, y) of the mosaic pixel at [0, 0] of a device image of the launch plan (regions are rebased)."""

@@ -40,3 +40,21 @@ def test_bench_two_ranks_on_one_gpu_gives_the_n1_catalog():
     assert all(r["tiles"] > 700 and r["mosaic_mb"] < 700 for r in out["per_rank"])       # each rank holds about half of the 1074 MB mosaic
     print("two ranks on one GPU (gloo): %.0f tiles/s, %d per-tile detections, %d sources (N = 1: the same, digest %s), per rank %s" % (
         out["value"], out["config"]["per_tile_detections"], out["config"]["sources_in_catalog"], one["config"]["catalog_sha1"][:12], out["per_rank"]))
+
+
+def test_record_gather_through_rccl_gives_the_n1_catalog():
+    """The collective of the N > 1 path on the real library: `CY_BENCH_FORCE_DIST=1` gives the N = 1 run a process group of ONE rank over
+    RCCL (backend nccl), so TileEngine.gather() issues `all_gather_into_tensor` through RCCL on the GPU, behind cy_detect_flush and the
+    stream-ordered record copies, with RCCL's own stream alive beside the context's four.  Same catalog digest as the plain run."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "CY_BENCH_BACKEND"):
+        env.pop(k, None)
+    plain = _bench(1, env)
+    env["CY_BENCH_FORCE_DIST"] = "1"
+    rccl = _bench(1, env)
+    assert plain["config"]["backend"] == "none" and rccl["config"]["backend"] == "nccl" and rccl["n_gpus"] == 1
+    for k in ("per_tile_detections", "sources_in_catalog", "tiles_skipped", "catalog_sha1"):
+        assert rccl["config"][k] == plain["config"][k], "%s: %r through RCCL, %r without" % (k, rccl["config"][k], plain["config"][k])
+    print("one-rank RCCL group: %.0f tiles/s (plain %.0f), gather %.3f ms, digest %s" % (
+        rccl["value"], plain["value"], rccl["step_split_ms_rank0"]["gather"], rccl["config"]["catalog_sha1"][:12]))

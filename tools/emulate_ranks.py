@@ -1,6 +1,10 @@
 """Time every rank's LOCAL share of the S16k grid at a given world size, one after the other on one GPU (developer tool):
-the N-GPU step time is max over ranks of this + gather + cross-tile merge.  python tools/emulate_ranks.py [world] [batch] [size] [rank,rank,...]"""
+the N-GPU step time is max over ranks of this + gather + cross-tile merge.  python tools/emulate_ranks.py [world] [batch] [size] [rank,rank,...]
+EMU_PG=1: a one-rank RCCL process group is initialised (eagerly, BEFORE the detector context exists) and every pass ends with the
+record all-gather through it -- the collective library's stream then lives beside the context's four, as in a real N > 1 run
+(GPU_MAX_HW_QUEUES=4 restores the HIP runtime's default queue count: the case that serialised two streams)."""
 import os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
@@ -9,6 +13,11 @@ ge.build()
 from caesar_yolo_amd import synth, utils, preprocessing as PP
 from caesar_yolo_amd.model import YOLO
 from caesar_yolo_amd.inference import TileEngine
+if os.environ.get("EMU_PG") == "1":
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 192
 size = int(sys.argv[3]) if len(sys.argv) > 3 else 16384
@@ -29,6 +38,10 @@ for r in only:
     for _ in range(reps):
         eng.run_local()
         torch.cuda.synchronize()
+        if os.environ.get("EMU_PG") == "1":          # this rank's record buffer through RCCL (a group of one: the engine's world is emulated)
+            out1 = torch.empty((1,) + tuple(eng.rec.shape), dtype=eng.rec.dtype, device=eng.rec.device)
+            dist.all_gather_into_tensor(out1, eng.rec)
+            torch.cuda.synchronize()
     dt = (time.time() - t) / reps
     worst = max(worst, dt)
     print("rank %d: %4d tiles, batches %s: %.2f ms (%.0f tiles/s)" % (r, eng.n_my, [(p[0], p[1], p[2]) for p in eng.plan], dt * 1e3, eng.n_my / dt))
