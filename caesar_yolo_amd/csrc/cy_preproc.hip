@@ -112,6 +112,34 @@ __device__ __forceinline__ double chain_value(const Smem& s, int upto, double ra
     return v;
 }
 
+// Is the chain's output for this raw pixel non-zero (= does the pixel count for a MINMAX stage behind the chain)?  Every stage but
+// the chain's last is evaluated exactly; of the last one only the zero test is needed, which has a closed form for the stages that end
+// in a division (ZSCALE) or a subtraction (BKG, SHIFT), so the pass of a [CLIP, ZSCALE, MINMAX] program costs two clamps and three
+// compares per pixel instead of a float64 division.
+__device__ __forceinline__ bool chain_nonzero(const Smem& s, int upto, float rf) {
+    if (!(rf != 0.0f) || !isfinite(rf)) return false;
+    double v = (double)rf;
+    for (int k = 0; k < upto; ++k) {
+        const double* sp = s.par + k * 4;
+        if (k + 1 == upto) {
+            switch (s.op[k]) {
+                case OP_BKG: return v != sp[0];                    // fl(v - m) == 0 iff v == m
+                case OP_SHIFT: return v > sp[0];                   // v - m, negatives clamped to 0
+                case OP_ZSCALE: {                                  // fmin(fmax((v - vmin) / rng, 0), 1) (no division when rng == 0)
+                    const double d = v - sp[0], rng = sp[1] - sp[0];
+                    if (!(d > 0.0) || rng < 0.0) return false;
+                    if (rng != 0.0 && d < rng * 1e-290) return d / rng > 0.0;     // (a quotient that could underflow: decided by the division itself)
+                    return true;
+                }
+                default: break;                                    // CLIP, HISTEQ, MINMAX: evaluated
+            }
+        }
+        v = apply_stage(s.op[k], s.q0[k], s.q1[k], sp, s.heq, v);
+        if (!cond_of(v)) return false;
+    }
+    return true;
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
@@ -340,6 +368,11 @@ struct Bracket { double vl, vh; bool on; float lf, hf; bool collect; };   // col
 // inside the bracket and below it; 3: + collect the raw keys of the members inside the bracket (s.cand / s.ncand).
 // Moments are accumulated branch-free (a pixel outside the set adds 0); a thread appends the candidates of a 4-pixel group
 // with ONE LDS atomic, and only when it has any (~15 % of the groups at the default bracket width).
+// Round 4: the loop was instruction-bound (37 instructions per pixel in its cheapest form: eight v_cndmask and seven scalar mask
+// operations per pixel around five float64 operations).  A group of four pixels whose members are ALL in the set -- the rule on a
+// radio tile outside its zero / NaN regions: a clip removes a fraction of a percent -- takes a branch-free path per lane: one
+// min3 / max3 range test for the group, no selects, the same additions in the same order (bit-identical sums).  Groups with an
+// excluded pixel, partial last groups of a row and the box mask take the general path.
 template <bool RAW, int MODE>
 __device__ __forceinline__ void moments_loop(Smem& s, const TileView& tv, int upto, const ClipSet& cs, double K, const Bracket& br,
                                              double& s1, double& s2, unsigned& ucnt, unsigned& below, unsigned& ucand) {
@@ -348,6 +381,7 @@ __device__ __forceinline__ void moments_loop(Smem& s, const TileView& tv, int up
     int y = (int)threadIdx.x / GR, gx = (int)threadIdx.x - y * GR;
     const int dy = NT / GR, dx = NT - dy * GR;
     const bool partial = (tv.tw & 3) != 0;                    // the last group of a row reaches past the tile
+    const bool plain = RAW && !partial && !cs.use_box;        // the fast path applies (uniform)
     for (int g0 = 0; g0 < NG; g0 += PXG * NT) {
         f32x4 r[PXG];
         int yy[PXG], xx[PXG];
@@ -362,42 +396,88 @@ __device__ __forceinline__ void moments_loop(Smem& s, const TileView& tv, int up
         }
 #pragma unroll
         for (int u = 0; u < PXG; ++u) {
-            double v[4];
-            bool act[4];
+            unsigned inmask = 0u;                                 // MODE >= 2: which of the group's pixels are set members inside the bracket
+            bool fast = false;
+            if (RAW && MODE != 1 && plain) {                  // (MODE 1 keeps the wave convergent around its ballot-aggregated histogram)
+                // all four members: smallest >= Lf, largest <= Uf, none zero (|r| of the smallest magnitude > 0), none NaN (min / max skip a
+                // NaN operand; the sum does not -- buffers that did not go through cy_mosaic_prepare may hold them)
+                const float r0 = r[u][0], r1 = r[u][1], r2 = r[u][2], r3 = r[u][3];
+                const float mn = fminf(fminf(r0, r1), fminf(r2, r3)), mx = fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+                const float am = fminf(fminf(fabsf(r0), fabsf(r1)), fminf(fabsf(r2), fabsf(r3)));
+                const float t4 = (r0 + r1) + (r2 + r3);
+                fast = mn >= cs.Lf && mx <= cs.Uf && am > 0.0f && t4 == t4;
+                if (fast) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float rf = r[u][e];
-                v[e] = RAW ? (double)rf : chain_value(s, upto, (double)rf);
-                bool a = RAW ? (rf != 0.0f && rf >= cs.Lf && rf <= cs.Uf) : (cond_of(v[e]) && v[e] >= cs.L && v[e] <= cs.U);
-                if (partial) a = a && (xx[u] + e < tv.tw);
-                if (cs.use_box) a = a && !(yy[u] >= cs.by0 && yy[u] < cs.by1 && xx[u] + e >= cs.bx0 && xx[u] + e < cs.bx1);
-                act[e] = a;
-            }
+                    for (int e = 0; e < 4; ++e) {
+                        const double d = (double)r[u][e] - K;
+                        s1 += d; s2 += d * d;
+                    }
+                    ucnt += 4u;
+                    if (MODE >= 2) {
+                        if (mx < br.lf) below += 4u;
+                        else if (mn <= br.hf) {                       // the group reaches into (or past) the bracket
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const double d = v[e] - K, dm = act[e] ? d : 0.0;
-                s1 += dm; s2 += dm * dm; ucnt += act[e] ? 1u : 0u;
+                            for (int e = 0; e < 4; ++e) {
+                                const float rf = r[u][e];
+                                inmask |= (rf >= br.lf && rf <= br.hf) ? (1u << e) : 0u;
+                                below += rf < br.lf ? 1u : 0u;
+                            }
+                        }
+                    }
+                }
             }
-            if (MODE == 1) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) hist_add(s.histA, fkey(r[u][e]) >> 21, act[e]);
-            }
-            if (MODE >= 2) {
-                bool inbr[4];
-                unsigned k = 0u;
+            if (!fast) {
+                double v[4];
+                bool act[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float rf = r[u][e];
-                    inbr[e] = act[e] && (RAW ? (rf >= br.lf && rf <= br.hf) : (v[e] >= br.vl && v[e] <= br.vh));
-                    below += (act[e] && (RAW ? rf < br.lf : v[e] < br.vl)) ? 1u : 0u;
-                    k += inbr[e] ? 1u : 0u;
+                    v[e] = RAW ? (double)rf : chain_value(s, upto, (double)rf);
+                    bool a = RAW ? (rf != 0.0f && rf >= cs.Lf && rf <= cs.Uf) : (cond_of(v[e]) && v[e] >= cs.L && v[e] <= cs.U);
+                    if (partial) a = a && (xx[u] + e < tv.tw);
+                    if (cs.use_box) a = a && !(yy[u] >= cs.by0 && yy[u] < cs.by1 && xx[u] + e >= cs.bx0 && xx[u] + e < cs.bx1);
+                    act[e] = a;
                 }
-                if (MODE == 2) ucand += k;
-                else if (k) {
-                    unsigned pos = atomicAdd(&s.ncand, k);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const double d = v[e] - K, dm = act[e] ? d : 0.0;
+                    s1 += dm; s2 += dm * dm; ucnt += act[e] ? 1u : 0u;
+                }
+                if (MODE == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hist_add(s.histA, fkey(r[u][e]) >> 21, act[e]);
+                }
+                if (MODE >= 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float rf = r[u][e];
+                        inmask |= (act[e] && (RAW ? (rf >= br.lf && rf <= br.hf) : (v[e] >= br.vl && v[e] <= br.vh))) ? (1u << e) : 0u;
+                        below += (act[e] && (RAW ? rf < br.lf : v[e] < br.vl)) ? 1u : 0u;
+                    }
+                }
+            }
+            if (MODE == 2) ucand += (unsigned)__popc(inmask);
+            if (MODE == 3) {
+                // the bracket's members are appended to s.cand with ONE LDS atomic per wave and group step: a per-lane atomicAdd on
+                // the single counter serialises in the LDS (15 % of the groups carry a candidate: ~15k same-address atomics per pass and
+                // workgroup, which is what a pass cost -- not its arithmetic).  Slots: pixel e of all lanes, then pixel e + 1.
+                if (__ballot(inmask != 0u) != 0ull) {                 // wave-uniform
+                    const int lane = (int)threadIdx.x & 63;
+                    const unsigned long long lt = (1ull << lane) - 1ull;
+                    unsigned long long m[4];
+                    unsigned tot = 0u, my[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        m[e] = __ballot(((inmask >> e) & 1u) != 0u);
+                        my[e] = tot + (unsigned)__popcll(m[e] & lt);
+                        tot += (unsigned)__popcll(m[e]);
+                    }
+                    unsigned base = 0u;
+                    if (lane == 0) base = atomicAdd(&s.ncand, tot);
+                    base = (unsigned)__shfl((int)base, 0);
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (inbr[e]) { if (pos < (unsigned)NCAND) s.cand[pos] = fkey(r[u][e]); ++pos; }
+                        if ((inmask >> e) & 1u) { const unsigned pos = base + my[e]; if (pos < (unsigned)NCAND) s.cand[pos] = fkey(r[u][e]); }
                 }
             }
         }
@@ -492,10 +572,53 @@ __device__ __forceinline__ ClipStats sigma_clip_run(Smem& s, const TileView& tv,
     // must still hold it.  Capacity NCAND = 24576 keys = 1.5 x the full width.
     constexpr double HALF_RANKS = 8192.0;
     Bracket br{0.0, 0.0, false, 0.0f, 0.0f, true};
+    // Round 4: the median of the INITIAL set used to cost three histogram passes (the level-0 radix histogram inside the first moments
+    // pass, then two more radix levels: ~100 VALU instructions per pixel each, 80 % of the kernel's vector instructions).  For a stage
+    // that reads the raw pixels a SAMPLE brackets it instead: the set members of every (th / 26)-th row (16k of the 410k pixels of a
+    // 640^2 tile, read as whole rows) go to s.cand, their 0.48 / 0.52 quantiles (radix select in LDS) bound the true median with
+    // ~5 sigma of the sampling error of a rank, and the first pass collects the set members between them like every later pass.
+    // A bracket that misses (or overflows) falls back to the histogram passes, so the median stays exact.
+    if (RAW) {
+        const int rstep = tv.th >= 52 ? tv.th / 26 : 1;
+        __syncthreads();
+        if (threadIdx.x == 0) s.ncand = 0u;
+        __syncthreads();
+        for (int y = rstep / 2; y < tv.th; y += rstep)
+            for (int x0 = 0; x0 < tv.tw; x0 += NT) {
+                const int x = x0 + (int)threadIdx.x;
+                float rf = 0.0f;
+                if (x < tv.tw) rf = tv.base[(size_t)y * tv.MW + x];
+                bool a = x < tv.tw && rf != 0.0f && isfinite(rf);
+                if (cs.use_box) a = a && !(y >= cs.by0 && y < cs.by1 && x >= cs.bx0 && x < cs.bx1);
+                const unsigned long long m = __ballot(a);                  // (whole waves stay in the loops)
+                if (m != 0ull) {
+                    const int lane = (int)threadIdx.x & 63;
+                    unsigned base = 0u;
+                    if (lane == 0) base = atomicAdd(&s.ncand, (unsigned)__popcll(m));
+                    base = (unsigned)__shfl((int)base, 0);
+                    const unsigned pos = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+                    if (a && pos < (unsigned)NCAND) s.cand[pos] = fkey(rf);
+                }
+            }
+        __syncthreads();
+        const unsigned ns = s.ncand < (unsigned)NCAND ? s.ncand : (unsigned)NCAND;
+        if (ns >= 4096u) {
+            unsigned keyA, keyB;
+            // 5 sigma of a sample rank: 2.5 / sqrt(ns) of the set (0.02 at 16k samples); at least +-1.5 %
+            double w = 2.5 / sqrt((double)ns);
+            if (w < 0.015) w = 0.015;
+            const unsigned long long ra = (unsigned long long)((0.5 - w) * (double)ns), rb = (unsigned long long)((0.5 + w) * (double)ns);
+            select_cand(s, ns, ra, rb < ns ? rb : ns - 1, &keyA, &keyB);
+            br.lf = fkey_inv(keyA); br.hf = fkey_inv(keyB);
+            br.vl = (double)br.lf; br.vh = (double)br.hf;
+            br.on = br.hf > br.lf; br.collect = true;
+        }
+        __syncthreads();
+    }
     int c = -2;                               // -2: first trip (about 0), -1: initial set about its median, >= 0: clips done
 #pragma unroll 1
     for (;;) {
-        const bool radix_trip = c == -2 || !br.on || !br.collect;   // this trip's median (if needed) comes from the radix select
+        const bool radix_trip = !br.on || !br.collect;   // this trip's median (if needed) comes from the radix select
         unsigned long long ts = pre_now();
         set_moments<RAW>(s, tv, upto, cs, K, radix_trip && c != -1, br, &n, &mean, &sd, &below, &ncand);
         pre_acc(0, ts);
@@ -715,11 +838,29 @@ __global__ __launch_bounds__(NT) void pre_stats_kernel(const PreArgs a) {
         } else if (op == OP_HISTEQ) {
             histeq_run(s, tv, k, heq);
         } else if (op == OP_MINMAX) {
-            double mn = INFINITY, mx = -INFINITY;
-            for_pixels<false>(s, tv, k, nullptr, [&](float, double v, bool, bool ok) {
-                if (ok && cond_of(v)) { mn = fmin(mn, v); mx = fmax(mx, v); }
-            });
-            o0 = block_min(s, mn); o1 = block_max(s, mx); o2 = p0; o3 = p1;
+            // min / max over the pixels whose stage input is non-zero and finite.  Every stage map is weakly increasing in its input and a
+            // pixel that hits 0 stays 0, so over those pixels the chain's output is a weakly increasing function of the RAW pixel: the
+            // extremes are the chain's values at the smallest and the largest such raw pixel.  The pass therefore only finds those two
+            // (fp32 min / max behind the non-zero test), and the chain is evaluated twice per tile instead of once per pixel.  A MINMAX
+            // stage with a reversed range inside the chain (decreasing map) takes the general pass.
+            bool increasing = true;
+            for (int j = 0; j < k; ++j) if (s.op[j] == OP_MINMAX && s.q1[j] < s.q0[j]) increasing = false;
+            if (increasing) {
+                float rmn = INFINITY, rmx = -INFINITY;
+                for_pixels<true>(s, tv, k, nullptr, [&](float rf, double, bool, bool ok) {
+                    if (ok && chain_nonzero(s, k, rf)) { rmn = fminf(rmn, rf); rmx = fmaxf(rmx, rf); }
+                });
+                const double a = block_min(s, (double)rmn), b = block_max(s, (double)rmx);
+                if (a <= b) { o0 = chain_value(s, k, a); o1 = chain_value(s, k, b); }
+                else { o0 = INFINITY; o1 = -INFINITY; }
+            } else {
+                double mn = INFINITY, mx = -INFINITY;
+                for_pixels<false>(s, tv, k, nullptr, [&](float, double v, bool, bool ok) {
+                    if (ok && cond_of(v)) { mn = fmin(mn, v); mx = fmax(mx, v); }
+                });
+                o0 = block_min(s, mn); o1 = block_max(s, mx);
+            }
+            o2 = p0; o3 = p1;
             if (!(o0 <= o1)) status = 1;           // no non-zero finite pixel: the stage returns None (preprocessing.py:101-103)
         }
         pre_acc(op == OP_ZSCALE ? 4 : (op == OP_HISTEQ ? 5 : (op == OP_MINMAX ? 6 : 3)), top);
