@@ -2758,7 +2758,9 @@ bool batch_invariant() { const char* e = getenv("CY_BATCH_INVARIANT"); return !e
 
 // fp16x3 context: the kernels that carry the three-pass K walk -- the 512-px wide 3x3 kernel (128- / 64-channel / dual-image forms),
 // the pixels-direct 1x1 / strided-3x3 kernel and the generic implicit GEMM for everything else.  The choice depends on the layer's
-// geometry only (never on the batch), so a tile's result does not depend on the batch it travels in.
+// geometry only, so a tile's result does not depend on the batch it travels in -- with one bound: the strip form addresses the
+// flattened batch with 22 bits (strip_fits: B * (H + 1) * (W + 1) < 2^22), which a launch can only exceed beyond the 4 GiB a tensor
+// may hold in this context (128 tiles of 640^2: 2^19.6 entries on the largest strip-form map), where cy_forward refuses the batch.
 static int conv_variant_x3(const ConvArgs& a) {
     const bool narrow = pad64(a.Cout) <= 64;
     if (a.k == 3 && a.s == 1 && a.c1 == 0 && !a.up0 && !a.out_f32 && a.Cin % 64 == 0 && a.wgt32 && a.out_bs == a.Ho * a.Wo && a.out_ro == 0) {

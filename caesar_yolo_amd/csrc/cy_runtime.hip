@@ -1231,6 +1231,14 @@ int cy_compact_records(const float* d_gathered, long long n_rows, const long lon
     return CY_OK;
 }
 
+int cy_compact_records_ctx(cy_ctx* c, const float* d_gathered, long long n_rows, const long long* d_perm, int T, int row_floats, int* d_hdr, float* d_out, void* stream) {
+    if (!c) return CY_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int rc = cy_compact_records(d_gathered, n_rows, d_perm, T, row_floats, d_hdr, d_out, stream);
+    if (rc != CY_OK) return fail(c, rc, "cy_compact_records failed (bad arguments or launch error)");
+    return CY_OK;
+}
+
 int cy_detect_counters(cy_ctx* c, long long* out4, int reset) {
     if (!c || !c->loaded || !out4) return fail(c, CY_ERR_ARG, "bad arguments");
     int h[4] = {0, 0, 0, 0};

@@ -18,7 +18,7 @@ EXPORTS = [
     "cy_create", "cy_destroy", "cy_last_error", "cy_load_weights", "cy_load_weights_mem", "cy_num_classes",
     "cy_weight_passes", "cy_class_name", "cy_plan_num_convs", "cy_plan_conv_desc", "cy_letterbox_geometry", "cy_num_anchors",
     "cy_pred_elems", "cy_profile_enable", "cy_profile_summary", "cy_profile_summary_lane", "cy_profile_layers", "cy_mosaic_prepare", "cy_letterbox_pack", "cy_preproc", "cy_preproc_planes", "cy_preproc_params", "cy_forward", "cy_debug_read_conv",
-    "cy_decode_nms", "cy_debug_stamps", "cy_debug_cand_counts", "cy_iou_merge", "cy_detect_tiles", "cy_detect_flush", "cy_detect_fence", "cy_compact_records", "cy_detect_counters", "cy_conv_bn_silu", "cy_bottleneck64", "cy_make_tile_records",
+    "cy_decode_nms", "cy_debug_stamps", "cy_debug_cand_counts", "cy_iou_merge", "cy_detect_tiles", "cy_detect_flush", "cy_detect_fence", "cy_compact_records", "cy_compact_records_ctx", "cy_detect_counters", "cy_conv_bn_silu", "cy_bottleneck64", "cy_make_tile_records",
     "cy_merge_edge_sources",
 ]
 
@@ -111,6 +111,7 @@ def load():
         "cy_detect_flush": (C.c_int, [vp, vp]),
         "cy_detect_fence": (C.c_int, [vp, vp]),
         "cy_compact_records": (C.c_int, [vp, C.c_longlong, vp, C.c_int, C.c_int, vp, vp, vp]),
+        "cy_compact_records_ctx": (C.c_int, [vp, vp, C.c_longlong, vp, C.c_int, C.c_int, vp, vp, vp]),
         "cy_detect_counters": (C.c_int, [vp, C.POINTER(C.c_longlong), C.c_int]),
         "cy_conv_bn_silu": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp, C.c_int, C.c_int, C.c_int,
                                       C.c_int, vp, vp, vp]),

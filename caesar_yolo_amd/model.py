@@ -259,8 +259,8 @@ class HipDetector(object):
         """gathered [R, rows, 1803] fp32, perm [T] int64 (row of tile t over all ranks) -> hdr [3T+1] int32, out [T*300*6] fp32 (device)."""
         T = int(perm.shape[0])
         rows = int(gathered.numel() // gathered.shape[-1])
-        self._chk(self.lib.cy_compact_records(self._p(gathered), rows, self._p(perm), T, int(gathered.shape[-1]), self._p(hdr), self._p(out),
-                                              self._stream()))
+        self._chk(self.lib.cy_compact_records_ctx(self.ctx, self._p(gathered), rows, self._p(perm), T, int(gathered.shape[-1]), self._p(hdr),
+                                                  self._p(out), self._stream()))
 
     def fence(self):
         """Work queued on the current stream since the last detect_tiles call (an upload into a mosaic buffer already in use, a

@@ -156,7 +156,11 @@ int cy_detect_flush(cy_ctx* ctx, void* stream);
  * the caller queues on `stream` between two unflushed calls -- a re-upload into a mosaic buffer already used, a memset of an
  * output buffer -- is NOT ordered before the internal streams touch those buffers: call cy_detect_fence after queuing it (the
  * next cy_detect_tiles then waits for it; costs the overlap of that one batch's preprocessing with the previous forward), or
- * prepare every buffer before the first call (what caesar_yolo_amd.inference.TileEngine does). */
+ * prepare every buffer before the first call (what caesar_yolo_amd.inference.TileEngine does).
+ * "A buffer this pipeline has seen" is its ADDRESS: a caching allocator (PyTorch's) may hand a NEW mosaic tensor the address of one
+ * freed inside the same unflushed pipeline, and that buffer then counts as seen although its upload is still queued on `stream`.
+ * A caller that allocates mosaic buffers between unflushed calls must call cy_detect_fence after every upload (uploads through
+ * cy_mosaic_prepare are fenced by the library itself). */
 int cy_detect_fence(cy_ctx* ctx, void* stream);
 
 /* Rank 0 after the gather (replaces the unpickling of the workers' source lists, caesar_yolo/inference.py:936-984): d_gathered holds
@@ -164,6 +168,9 @@ int cy_detect_fence(cy_ctx* ctx, void* stream);
  * d_perm[t] = row index (over all ranks) of tile t (an index outside [0, n_rows) makes tile t a rejected tile with status CY_ERR_ARG).  Writes d_hdr = {count[T] (0 for a rejected tile) | status[T] | exclusive prefix[T] | total}
  * (3 T + 1 ints) and the valid detections in tile-id order into d_out (room for T * 300 * 6 floats): what cy_make_tile_records takes. */
 int cy_compact_records(const float* d_gathered, long long n_rows, const long long* d_perm, int T, int row_floats, int* d_hdr, float* d_out, void* stream);
+/* the same with the context named: launches on the context's device whatever device is current (the form above launches on the
+ * CURRENT device: the caller must have selected the device that owns the buffers) */
+int cy_compact_records_ctx(cy_ctx* ctx, const float* d_gathered, long long n_rows, const long long* d_perm, int T, int row_floats, int* d_hdr, float* d_out, void* stream);
 
 /* events the reference would not survive silently, accumulated over cy_decode_nms / cy_iou_merge / cy_detect_tiles calls:
  * out4[0] degenerate boxes (x1 >= x2 or y1 >= y2) dropped before the IoU merge -- the reference aborts on them inside

@@ -24,6 +24,13 @@ def s16k():
 
 def config_input(name):
     """-> (image fp32 [H,W], tile size, step fraction, imgsz, stage spec) of a BASELINE config at reduced size."""
+    if name == "C1":      # test/galaxy0001.fits as ONE frame (132 x 132 -> LetterBox resize to 640 x 640), test/run_inference.sh:6-10 with BASELINE thresholds
+        if "c1" not in _CACHE:
+            import os
+            from caesar_yolo_amd import utils
+            data, _ = utils.read_fits_image(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "galaxy0001.fits"))
+            _CACHE["c1"] = np.ascontiguousarray(np.array(data, np.float32))
+        return _CACHE["c1"], 132, 1.0, 640, ZS_MINMAX
     if name == "C2":      # stand-in for the missing cutout: crop of S16k at (6144, 6144); 512x512 tiles, step 1.0 -> 16 tiles
         return np.ascontiguousarray(s16k()[6144:8192, 6144:8192]), 512, 1.0, 512, ZS_MINMAX
     if name == "C3":      # crop at (204, 204): tile 2 of rows/columns starts at 1024 = the all-zero block -> two rejected tiles;

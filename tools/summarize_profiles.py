@@ -114,13 +114,13 @@ with open(os.path.join(P, trk + "_summary.md"), "w") as fp:
             if "conv3x3_widep_kernel<false,false,0>" in n or "conv3x3_widep_kernel<false,true,0>" in n:
                 pers[0] += 1; pers[1] += d
                 continue
-            if "conv3x3_wide_kernel<true,2,false,2,false>" not in n:
+            if "conv3x3_wide_kernel<true,2,false,2,false" not in n:
                 continue
             wgs = int(row.get("Grid_Size_X", row.get("Grid_Size", 0))) // 512
             tgt = main if wgs >= 1000 else small
             tgt[0] += 1; tgt[1] += d
         if main[0]:
-            fp.write("Same split in the rocprofv3 kernel trace below: `conv3x3_wide_kernel<true, 2, false, 2, false>` full batches %d launches, avg %.1f us; "
+            fp.write("Same split in the rocprofv3 kernel trace below: `conv3x3_wide_kernel<true, 2, false, 2, false, 0>` full batches %d launches, avg %.1f us; "
                      "its persistent form `conv3x3_widep_kernel<false, *, 0>` (18-stage layers of the full batches) %d launches, avg %.1f us; both together "
                      "%d launches, avg %.1f us; small-batch lane %d launches, avg %.1f us (bench.py's hipEvent average over the full batches, both forms: %.1f us).\n\n"
                      % (main[0], main[1] / main[0], pers[0], (pers[1] / pers[0]) if pers[0] else 0.0, main[0] + pers[0],
