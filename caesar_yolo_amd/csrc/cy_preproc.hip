@@ -131,10 +131,57 @@ __device__ __forceinline__ bool chain_nonzero(const Smem& s, int upto, float rf)
                     if (rng != 0.0 && d < rng * 1e-290) return d / rng > 0.0;     // (a quotient that could underflow: decided by the division itself)
                     return true;
                 }
-                default: break;                                    // CLIP, HISTEQ, MINMAX: evaluated
+                case OP_HISTEQ: return true;                       // interpolated cdf of a non-zero finite value: >= cdf[0] = (count of the first bin >= 1) / n > 0
+                default: break;                                    // CLIP, MINMAX: evaluated
             }
         }
         v = apply_stage(s.op[k], s.q0[k], s.q1[k], sp, s.heq, v);
+        if (!cond_of(v)) return false;
+    }
+    return true;
+}
+
+// The same test with the chain's operators and parameters in scalar registers (read from LDS once per pass instead of per pixel and
+// stage: a dependent ds_read per stage made a MINMAX pass 2.5x as long as a moments pass): chains of up to three stages made of
+// BKG / SHIFT / CLIP / ZSCALE, the last stage by its closed-form zero test.  ok = false: the chain is not of that kind (chain_nonzero).
+struct NzChain { int n; int op[3]; double a[3], b[3]; bool ok; };
+__device__ __forceinline__ double uniform_double(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(u & 0xFFFFFFFFull)), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ NzChain nz_chain(const Smem& s, int upto) {
+    NzChain c{};
+    c.n = upto; c.ok = upto <= 3;
+    for (int k = 0; k < 3; ++k) {
+        c.op[k] = k < upto ? __builtin_amdgcn_readfirstlane(s.op[k]) : 0;
+        c.a[k] = uniform_double(k < upto ? s.par[k * 4] : 0.0); c.b[k] = uniform_double(k < upto ? s.par[k * 4 + 1] : 0.0);
+        if (k < upto && c.op[k] != OP_BKG && c.op[k] != OP_SHIFT && c.op[k] != OP_CLIP && c.op[k] != OP_ZSCALE &&
+            !(c.op[k] == OP_HISTEQ && k + 1 == upto)) c.ok = false;       // (HISTEQ only as the last stage: its value is never zero)
+        if (k + 1 < upto && c.op[k] == OP_ZSCALE) c.ok = false;      // (a ZSCALE in the middle of a chain needs its quotient: general path)
+    }
+    return c;
+}
+__device__ __forceinline__ bool nz_test(const NzChain& c, float rf) {
+    if (!(rf != 0.0f) || !isfinite(rf)) return false;
+    double v = (double)rf;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (k >= c.n) break;
+        const bool last = k + 1 == c.n;
+        switch (c.op[k]) {
+            case OP_BKG: if (last) return v != c.a[k]; v = v - c.a[k]; break;
+            case OP_SHIFT: if (last) return v > c.a[k]; v = v - c.a[k]; if (v < 0.0) return false; break;
+            case OP_CLIP: if (v < c.a[k]) v = c.a[k]; if (v > c.b[k]) v = c.b[k]; break;
+            case OP_HISTEQ: return true;                           // (last stage by construction; see chain_nonzero)
+            case OP_ZSCALE: {                                      // (last stage by construction)
+                const double d = v - c.a[k], rng = c.b[k] - c.a[k];
+                if (!(d > 0.0) || rng < 0.0) return false;
+                if (rng != 0.0 && d < rng * 1e-290) return d / rng > 0.0;
+                return true;
+            }
+            default: break;
+        }
         if (!cond_of(v)) return false;
     }
     return true;
@@ -382,18 +429,28 @@ __device__ __forceinline__ void moments_loop(Smem& s, const TileView& tv, int up
     const int dy = NT / GR, dx = NT - dy * GR;
     const bool partial = (tv.tw & 3) != 0;                    // the last group of a row reaches past the tile
     const bool plain = RAW && !partial && !cs.use_box;        // the fast path applies (uniform)
+    // The groups of step i + 1 are requested before those of step i are consumed (register double buffer): with the arithmetic of a
+    // step down to ~1 us (round 4) the ~2 us a step waited for its own loads were two thirds of a pass.
+    f32x4 rn[PXG];
+    int yn[PXG], xn[PXG];
+    auto request = [&](int g0) {
+#pragma unroll
+        for (int u = 0; u < PXG; ++u) {
+            const int g = g0 + u * NT + (int)threadIdx.x;
+            yn[u] = y; xn[u] = gx << 2;
+            const unsigned off = g < NG ? (unsigned)(y * tv.MW + (gx << 2)) * 4u : 0xFFFFFF00u;   // past the end: zeros = not in any set
+            rn[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(tv.rs, off, 0, 0));
+            gx += dx; y += dy;
+            if (gx >= GR) { gx -= GR; ++y; }
+        }
+    };
+    request(0);
     for (int g0 = 0; g0 < NG; g0 += PXG * NT) {
         f32x4 r[PXG];
         int yy[PXG], xx[PXG];
 #pragma unroll
-        for (int u = 0; u < PXG; ++u) {
-            const int g = g0 + u * NT + (int)threadIdx.x;
-            yy[u] = y; xx[u] = gx << 2;
-            const unsigned off = g < NG ? (unsigned)(y * tv.MW + (gx << 2)) * 4u : 0xFFFFFF00u;   // past the end: zeros = not in any set
-            r[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(tv.rs, off, 0, 0));
-            gx += dx; y += dy;
-            if (gx >= GR) { gx -= GR; ++y; }
-        }
+        for (int u = 0; u < PXG; ++u) { r[u] = rn[u]; yy[u] = yn[u]; xx[u] = xn[u]; }
+        if (g0 + PXG * NT < NG) request(g0 + PXG * NT);
 #pragma unroll
         for (int u = 0; u < PXG; ++u) {
             unsigned inmask = 0u;                                 // MODE >= 2: which of the group's pixels are set members inside the bracket
@@ -847,9 +904,16 @@ __global__ __launch_bounds__(NT) void pre_stats_kernel(const PreArgs a) {
             for (int j = 0; j < k; ++j) if (s.op[j] == OP_MINMAX && s.q1[j] < s.q0[j]) increasing = false;
             if (increasing) {
                 float rmn = INFINITY, rmx = -INFINITY;
-                for_pixels<true>(s, tv, k, nullptr, [&](float rf, double, bool, bool ok) {
-                    if (ok && chain_nonzero(s, k, rf)) { rmn = fminf(rmn, rf); rmx = fmaxf(rmx, rf); }
-                });
+                const NzChain nz = nz_chain(s, k);
+                if (nz.ok) {
+                    for_pixels<true>(s, tv, k, nullptr, [&](float rf, double, bool, bool ok) {
+                        if (ok && nz_test(nz, rf)) { rmn = fminf(rmn, rf); rmx = fmaxf(rmx, rf); }
+                    });
+                } else {
+                    for_pixels<true>(s, tv, k, nullptr, [&](float rf, double, bool, bool ok) {
+                        if (ok && chain_nonzero(s, k, rf)) { rmn = fminf(rmn, rf); rmx = fmaxf(rmx, rf); }
+                    });
+                }
                 const double a = block_min(s, (double)rmn), b = block_max(s, (double)rmx);
                 if (a <= b) { o0 = chain_value(s, k, a); o1 = chain_value(s, k, b); }
                 else { o0 = INFINITY; o1 = -INFINITY; }
