@@ -20,28 +20,13 @@ constexpr int MAX_NMS = 30000;       // ultralytics max_nms
 constexpr float MAX_WH = 7680.0f;    // ultralytics max_wh (class offset)
 
 // ------------------------------------------------------------------------------------------------ decode
-// One thread per anchor.  STAGED (round 4): the head output of a workgroup's 256 consecutive anchors is ONE contiguous run of
-// 256 x (64 + nc) floats; it is copied to LDS with coalesced 16-byte loads first and every thread then reads its anchor's row from
-// there (row stride 64 + nc words: odd for nc = 5, conflict-free).  Read in place, a thread's five class logits are 276 bytes from its
-// neighbour's: every wave-load touched 64 cache lines, and the kernel moved 0.47 TB/s (432 us per 256 tiles of 512^2).  The arithmetic
-// per anchor is unchanged, operation for operation.  !STAGED: the in-place form (rows too large for LDS, unaligned runs).
-template <bool STAGED>
+// One thread per anchor, class logits first.  Alone on the GPU the kernel takes 59 us per 256 tiles of 512^2 (it touches the cache
+// lines that hold the class logits: 190 MB, 3.2 TB/s); inside the pipelined pass, on the low-priority post-processing stream beside the
+// conv stack, its launches last ~430 us.  Round 4 tried a STAGED form (a workgroup's 256 x 69 floats copied to LDS with coalesced
+// 16-byte loads, rows read from there): it moves twice the bytes and 70 KB of LDS per workgroup: 111 us alone, 590 us in the pass.
 __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float srow[];
     const int b = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    const int rowf = 64 + a.nc;
-    if (STAGED) {
-        const int i0 = blockIdx.x * 256;
-        const int na = a.A - i0 < 256 ? a.A - i0 : 256;
-        const size_t first = ((size_t)b * a.A + i0) * rowf;              // (a multiple of 4 floats: checked by launch_decode)
-        const int nvec = (na * rowf) >> 2, ntail = (na * rowf) & 3;
-        typedef float f32x4 __attribute__((ext_vector_type(4)));
-        const f32x4* src = reinterpret_cast<const f32x4*>(a.pred + first);
-        for (int v = threadIdx.x; v < nvec; v += 256) reinterpret_cast<f32x4*>(srow)[v] = src[v];
-        if ((int)threadIdx.x < ntail) srow[nvec * 4 + threadIdx.x] = a.pred[first + (size_t)nvec * 4 + threadIdx.x];
-        __syncthreads();
-    }
     if (i >= a.A) return;
     // anchor -> (level, y, x): levels are concatenated stride 8, 16, 32, each row-major
     int lvl = 0, r = i;
@@ -50,7 +35,7 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs a) {
     const int gw = a.lvl_w[lvl];
     const float ax = (float)(r % gw) + 0.5f, ay = (float)(r / gw) + 0.5f;
     const float stride = (float)(8 << lvl);
-    const float* p = STAGED ? srow + (size_t)threadIdx.x * rowf : a.pred + ((size_t)b * a.A + i) * rowf;
+    const float* p = a.pred + ((size_t)b * a.A + i) * (64 + a.nc);
     // class scores first: most anchors fail the confidence test and skip the DFL work
     float best = -1.0f; int bj = 0;
     for (int c = 0; c < a.nc; ++c) {
@@ -87,18 +72,7 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs a) {
 
 hipError_t launch_decode(const DecodeArgs& a, hipStream_t s) {
     if (a.A >= 65536 || a.cap >= 65536) return hipErrorInvalidValue;     // key packing below: 16 + 16 bits
-    const size_t lds = (size_t)256 * (64 + a.nc) * sizeof(float);
-    // staged form: the rows of a workgroup fit in LDS (nc <= 90) and every workgroup's run starts on a 16-byte boundary
-    // (A * (64 + nc) and 256 * (64 + nc) multiples of 4 floats, the tensor itself 16-byte aligned)
-    const bool staged = env_knob("CY_DECODE_STAGED", 1) && lds <= 160 * 1024 - 1024 && ((size_t)a.A * (64 + a.nc)) % 4 == 0 &&
-                        (reinterpret_cast<uintptr_t>(a.pred) & 15) == 0;
-    if (staged) {
-        static bool attr_set = false;
-        if (!attr_set) { hipFuncSetAttribute(reinterpret_cast<const void*>(decode_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); attr_set = true; }
-        hipLaunchKernelGGL(decode_kernel<true>, dim3((a.A + 255) / 256, a.B), dim3(256), lds, s, a);
-    } else {
-        hipLaunchKernelGGL(decode_kernel<false>, dim3((a.A + 255) / 256, a.B), dim3(256), 0, s, a);
-    }
+    hipLaunchKernelGGL(decode_kernel, dim3((a.A + 255) / 256, a.B), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
