@@ -139,7 +139,9 @@ with open(os.path.join(P, trk + "_summary.md"), "w") as fp:
     fp.write("| kernel | calls | avg us | MiB per launch | GB/s | of 8 TB/s | % of GPU time |\n|---|---|---|---|---|---|---|\n")
     for k, v in sorted(side.items(), key=lambda kv: -kv[1]["share_of_gpu_time_pct"]):
         fp.write("| `%s` | %d | %.1f | %.2f | %.0f | %.3f | %.2f |\n" % (k, v["calls"], v["avg_us"], v["hbm_bytes_per_launch"] / 2 ** 20, v["GB_per_s"], v["frac_of_8TBps"], v["share_of_gpu_time_pct"]))
-    fp.write("\n(these kernels are latency-bound by design -- a few dozen workgroups beside the conv stack; the figure says how far from the roof that leaves them)\n")
+    fp.write("\n(durations are those INSIDE the pipelined pass: these kernels run on low-priority side streams beside the conv stack and are latency-bound by design -- "
+             "a few dozen workgroups; alone on the GPU `decode_kernel` takes 59 us per 256 tiles of 512^2 = 3.2 TB/s over the cache lines it touches "
+             "(`tools/time_post.py` under rocprofv3), seven times faster than its launches in the pass)\n")
     fp.write("\n## SQ counters (bench.py --size 8192, one pass; sums over the dispatches of each kernel)\n\n")
     fp.write("| kernel | n | MFMA busy / (4 x BUSY_CU-ish) | WAIT_ANY/WAVE | WAIT_INST/WAVE | ACTIVE/WAVE | LDS conflict / LDS active |\n|---|---|---|---|---|---|---|\n")
     for k, v in sorted(sq.items(), key=lambda kv: -kv[1].get("SQ_BUSY_CYCLES", 0))[:10]:
