@@ -139,3 +139,15 @@ print(len(det), out.shape[0], hashlib.sha256(np.ascontiguousarray(out).tobytes()
     assert len(res) == 1, res
     n_in, n_out = [int(v) for v in res.pop().split()[:2]]
     assert n_in >= 40000 and 0 < n_out < n_in
+
+
+def test_package_import_raises_the_hip_queue_count():
+    """Importing the package (before any HIP call) asks the HIP runtime for eight hardware queues: a context's four streams plus a
+    collective library's otherwise share four (profiles/r04_stream_budget.md).  An explicit setting wins."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import os, sys; sys.path.insert(0, %r); import caesar_yolo_amd; print(os.environ['GPU_MAX_HW_QUEUES'])" % root
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    assert subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, text=True, check=True).stdout.strip() == "8"
+    env["GPU_MAX_HW_QUEUES"] = "4"
+    assert subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, text=True, check=True).stdout.strip() == "4"
