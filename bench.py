@@ -588,11 +588,13 @@ def run_rank(args):
                         hb = (q, byt, bsrc, bset)
             if hb:
                 q, byt, bsrc, bset = hb
+                if bset != "main" and prof_all and q["kernel"] in prof_all:
+                    q = prof_all[q["kernel"]]           # bytes averaged over ALL launches (a persistent kernel's launches cannot be split by grid size): time over all launches too
                 tbs = byt * q["launches"] / (q["ms"] * 1e-3) / 1e12
                 out["roofline_hbm"] = {"kernel": q["kernel"], "bound": "hbm", "achieved": tbs, "peak": 8.0, "unit": "TB/s", "frac": tbs / 8.0,
                                        "traffic": byt, "launches": q["launches"], "avg_launch_ms": q["ms"] / q["launches"],
                                        "traffic_source": "%s (2 x FETCH_SIZE + WRITE_SIZE per launch, separate rocprofv3 --pmc passes, averaged over %s; launch "
-                                                         "times: hipEvents of this run, full-batch launches)" % (
+                                                         "times: hipEvents of this run over the same launch set)" % (
                                                              bsrc, "the full-batch launches (same launch set as the times)" if bset == "main" else
                                                              "ALL launches incl. the small-batch lane (a persistent kernel's launches cannot be told apart by grid size)"),
                                        "traffic_launch_set": bset,

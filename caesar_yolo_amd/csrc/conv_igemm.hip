@@ -21,6 +21,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 namespace cy {
 
@@ -2413,8 +2414,16 @@ static hipError_t launch_strip(const ConvArgs& a, hipStream_t s) {
 // chunks ahead, counted vmcnt).  A wave owns MI*16 pixels x all BN = 64*NB channels of the workgroup's tile:
 //   per 64-channel K chunk and wave: NB DMA pieces + 2*MI register loads for 8*NB*MI MFMAs (NB=4, MI=2: 8 for 64).
 // Also handles the two-segment input (nearest-x2 upsample + concat) of layers 12 and 15: per-lane addresses anyway.
-template <int NB, int MI, int RING, bool K3, bool SPLIT = false, int NDW = 8>
+// FUSE2 (round 4; NB = 4, the tile holds all 256 output channels of its pixels): back-to-back fusion with the 1x1 convolution that is
+// this layer's only reader (yolov8 model.3 -> model.4.cv1).  After the K loop a lane holds, per 64-channel block g, the 16 contiguous
+// channels 64 g + 16 fq + 0..15 of its pixels: bias + SiLU, rounded to fp16 exactly as the store would, they ARE the MFMA B operand of
+// the second GEMM for K chunk g once that layer's input channels are permuted at pack time (pack_weights_fused2) -- no LDS, no lane
+// movement.  The second layer's four weight chunks (128 KB) are requested into the dead ring (+ one slot) right behind the loop and
+// land under the first epilogue's arithmetic; its result is stored through the same epilogue form.  The 256-channel map between the
+// two layers (2 MB per 512^2 tile) is never written or read.
+template <int NB, int MI, int RING, bool K3, bool SPLIT = false, int NDW = 8, bool FUSE2 = false>
 __global__ __launch_bounds__(512, (NB * MI <= 4 && RING == 2) ? 2 : 1) void conv1x1_direct_kernel(const ConvArgs a) {
+    static_assert(!FUSE2 || (NB == 4 && !SPLIT), "back-to-back fusion: 256-channel tile, fp16 context");
     // NDW = number of waves that request the weight chunks (LDS-DMA): 8 = every wave its share; 4 = waves 0-3 only (one per SIMD),
     // so that a request waiting for room in the memory pipeline holds one wave of a SIMD while its partner keeps the matrix pipe busy
     // SPLIT (fp16x3 context): three passes over the K chunks -- pixels [x_lo | x_hi | x_hi] (the low halves a.in*_lo halves behind
@@ -2543,7 +2552,7 @@ __global__ __launch_bounds__(512, (NB * MI <= 4 && RING == 2) ? 2 : 1) void conv
     for (int ni = 0; ni < NB * 4; ++ni)
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto compute = [&](int slot) {
+    auto compute_x = [&](int slot, const u32x4 (&xs)[MI][2]) {
         const char* Wb = smem + slot * W_BYTES;
         // 2*NB groups of (4 weight fragments, 4*MI MFMAs); the fragments of group i+1 are read before the MFMAs of group i
         f16x8 wb[2][4];
@@ -2567,14 +2576,15 @@ __global__ __launch_bounds__(512, (NB * MI <= 4 && RING == 2) ? 2 : 1) void conv
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
                     acc[g * 4 + ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
-                        wb[gi & 1][ni], __builtin_bit_cast(f16x8, xa[slot][mi][kk]), acc[g * 4 + ni][mi], 0, 0, 0);
+                        wb[gi & 1][ni], __builtin_bit_cast(f16x8, xs[mi][kk]), acc[g * 4 + ni][mi], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+    auto compute = [&](int slot) { compute_x(slot, xa[slot]); };
 
     // the tile's BN bias values -> LDS with the very first request (wave 0; oldest request: every counted wait covers it), so
     // that the epilogue does not start with an exposed L2 round trip
-    float* const bias_lds = reinterpret_cast<float*>(smem + RING * W_BYTES);
+    float* const bias_lds = reinterpret_cast<float*>(smem + (FUSE2 ? 4 : RING) * W_BYTES);
     if (wave == 0) {
         const auto rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, (unsigned)pad64(a.Cout) * 4u, 0x00020000);
         dma_piece(rsb, (lds_ptr_t*)bias_lds, lane * 16 < BN * 4 ? (unsigned)(n0 * 4 + lane * 16) : CY_OOB, 0);
@@ -2610,6 +2620,87 @@ __global__ __launch_bounds__(512, (NB * MI <= 4 && RING == 2) ? 2 : 1) void conv
     }
 
     const unsigned long long t_epi = stamps ? stamp_real() : 0, c_epi = stamps ? stamp_now() : 0;
+    if constexpr (FUSE2) {
+        // every wave is past the loop's last barrier: the ring is free.  Second layer: chunks 0..3 -> slots 0..3 (the launch gives
+        // this form a fourth slot), bias2 behind the first bias
+        const auto rsw2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wgt2), 0, a.wgt2_bytes, 0x00020000);
+        const int cpad2 = pad128(a.cout2);
+        if ((NDW == NW || reqw)) {
+#pragma unroll
+            for (int c2 = 0; c2 < 4; ++c2)
+#pragma unroll
+                for (int j = 0; j < WPW; ++j)
+                    dma_piece(rsw2, (lds_ptr_t*)(smem + c2 * W_BYTES + (j * NDW + wave) * 1024), woff0, c2 * cpad2 * 128 + j * NDW * 1024);
+        }
+        float* const bias2_lds = reinterpret_cast<float*>(smem + 4 * W_BYTES) + 256;
+        if (wave == 0) {
+            const auto rsb2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias2), 0, (unsigned)pad64(a.cout2) * 4u, 0x00020000);
+            dma_piece(rsb2, (lds_ptr_t*)bias2_lds, lane * 16 < BN * 4 ? (unsigned)(lane * 16) : CY_OOB, 0);
+        }
+        // first epilogue in registers: bias + SiLU, rounded to fp16 like the store it replaces -> B fragments of the second GEMM
+        float* const bias1_lds = reinterpret_cast<float*>(smem + 4 * W_BYTES);
+        u32x4 x2[4][MI][2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float bv[16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(bias1_lds + g * 64 + fq * 16 + j * 4);
+                bv[j * 4] = t[0]; bv[j * 4 + 1] = t[1]; bv[j * 4 + 2] = t[2]; bv[j * 4 + 3] = t[3];
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                float v[16];
+                bias_act16(acc[g * 4][mi], acc[g * 4 + 1][mi], acc[g * 4 + 2][mi], acc[g * 4 + 3][mi], bv, a.act != 0, v);
+                f16x8 h0, h1;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { h0[j] = (f16)v[j]; h1[j] = (f16)v[8 + j]; }
+                x2[g][mi][0] = __builtin_bit_cast(u32x4, h0); x2[g][mi][1] = __builtin_bit_cast(u32x4, h1);
+            }
+        }
+#pragma unroll
+        for (int ni = 0; ni < NB * 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+        CY_WAIT_VM(0);
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int c2 = 0; c2 < 4; ++c2) compute_x(c2, x2[c2]);
+        // second epilogue: bias2 + activation, 16 contiguous channels per lane and 64-channel block
+#pragma unroll
+        for (int g = 0; g < NB; ++g) {
+            const int cbase = g * 64 + fq * 16;
+            if (cbase >= pad64(a.cout2)) continue;
+            float bv[16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(bias2_lds + g * 64 + fq * 16 + j * 4);
+                bv[j * 4] = t[0]; bv[j * 4 + 1] = t[1]; bv[j * 4 + 2] = t[2]; bv[j * 4 + 3] = t[3];
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int m = m0 + (wave * MI + mi) * 16 + fr;
+                if (m >= M) continue;
+                const int b = m / HoWo, r = m - b * HoWo;
+                const long opix = (long)b * a.out_bs + a.out_ro + r;
+                float v[16];
+                bias_act16(acc[g * 4][mi], acc[g * 4 + 1][mi], acc[g * 4 + 2][mi], acc[g * 4 + 3][mi], bv, a.act2 != 0, v);
+                f16* dst = reinterpret_cast<f16*>(a.out2) + opix * a.out2_ct + a.out2_coff + cbase;
+                if (cbase + 16 <= a.cout2) {
+                    f16x8 o0, o1;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { o0[j] = (f16)v[j]; o1[j] = (f16)v[8 + j]; }
+                    *reinterpret_cast<f16x8*>(dst) = o0;
+                    *reinterpret_cast<f16x8*>(dst + 8) = o1;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j)
+                        if (cbase + j < a.cout2) dst[j] = (f16)v[j];
+                }
+            }
+        }
+        return;
+    }
     // ---- epilogue: per 64-channel block the same 16-contiguous-channels-per-lane layout as the other kernels
 #pragma unroll
     for (int g = 0; g < NB; ++g) {
@@ -2688,18 +2779,18 @@ __global__ __launch_bounds__(512, (NB * MI <= 4 && RING == 2) ? 2 : 1) void conv
     }
 }
 
-template <int NB, int MI, int RING, bool K3, bool SPLIT = false, int NDW = 8>
+template <int NB, int MI, int RING, bool K3, bool SPLIT = false, int NDW = 8, bool FUSE2 = false>
 static hipError_t launch_direct(const ConvArgs& a, hipStream_t s) {
     constexpr int BN = 64 * NB, BM = 8 * MI * 16;
-    const size_t lds = RING * BN * 128 + 1024;             // weight ring, bias
+    const size_t lds = (FUSE2 ? 4 : RING) * BN * 128 + 2048;             // weight ring (four slots for the second layer of a fused pair), bias (x2)
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_direct_kernel<NB, MI, RING, K3, SPLIT, NDW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_direct_kernel<NB, MI, RING, K3, SPLIT, NDW, FUSE2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const int M = a.B * a.Ho * a.Wo;
     const int blocks = ((M + BM - 1) / BM) * ((pad64(a.Cout) + BN - 1) / BN);
-    hipLaunchKernelGGL((conv1x1_direct_kernel<NB, MI, RING, K3, SPLIT, NDW>), dim3(blocks), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((conv1x1_direct_kernel<NB, MI, RING, K3, SPLIT, NDW, FUSE2>), dim3(blocks), dim3(512), lds, s, a);
     return hipGetLastError();
 }
 
@@ -2897,6 +2988,9 @@ hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s) {
             // weight requests on 4 waves (one per SIMD) or on all 8 (CY_DIRECT_NDW forces one; same bits either way).  Measured per layer
             // at batch 256: four requesting waves are 2-5 % faster on the strided 3x3 layers (model.5, model.7) and 1-6 % slower on the 1x1s
             static const int ndw = env_knob("CY_DIRECT_NDW", 0);
+            // back-to-back pair (the runtime sets wgt2 when this layer's only reader is a 256 -> <= 256 1x1 and the tile holds all channels)
+            if (a.wgt2 && pad64(a.Cout) == 256 && a.c1 == 0 && !a.res && !a.out_f32)
+                return a.k == 3 ? launch_direct<4, 2, 3, true, false, 4, true>(a2, s) : launch_direct<4, 2, 3, false, false, 8, true>(a2, s);
             if (a.k == 3) return ndw == 8 ? launch_direct<4, 2, 3, true>(a2, s) : launch_direct<4, 2, 3, true, false, 4>(a2, s);
             return ndw == 4 ? launch_direct<4, 2, 3, false, false, 4>(a2, s) : launch_direct<4, 2, 3, false>(a2, s);
         }
@@ -2956,6 +3050,17 @@ void pack_weights(Precision p, const float* W, int cout, int cin, int k, void* d
             }
     }
     (void)chunks;
+}
+
+// second layer of a back-to-back pair: 1x1 weights with the input channels in the accumulator order of the first layer's kernel
+void pack_weights_fused2(const float* W2, int cout2, int cin2, void* dst) {
+    std::vector<float> perm((size_t)cout2 * cin2);
+    for (int n = 0; n < cout2; ++n)
+        for (int p = 0; p < cin2; ++p) {
+            const int c = p >> 6, kk = (p >> 5) & 1, q = (p >> 3) & 3, j = p & 7;
+            perm[(size_t)n * cin2 + p] = W2[(size_t)n * cin2 + 64 * c + 16 * q + 8 * kk + j];
+        }
+    pack_weights(PREC_F16, perm.data(), cout2, cin2, 1, dst);
 }
 
 // fp16x3 context.  Per output channel n the filter is scaled by 2^e(n) so that its largest weight lies in [2^13, 2^14): the low

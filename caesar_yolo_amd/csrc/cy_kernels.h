@@ -47,6 +47,12 @@ struct ConvArgs {
     // the power of two that undoes the weight scale of output channel n (applied to the accumulator before the bias).
     int split, in0_lo, in1_lo, out_lo, res_lo;
     const float* oscale;                               // [Cout_pad128] or null
+    // back-to-back fusion (fp16 context, pixels-direct kernel with a 256-channel tile that holds ALL output channels of its pixels): the
+    // fused Conv+bias+SiLU result of this layer is not stored but multiplied, in registers, by the 1x1 convolution that is its only
+    // reader: wgt2 = that layer's packed weights with its INPUT channels permuted to the accumulator order of the kernel
+    // (pack_weights_fused2), bias2 / act2 / out2* its bias, activation and destination slice (same pixel grid).  wgt2 == null: off.
+    const void* wgt2; uint32_t wgt2_bytes; const float* bias2; int act2, cout2;
+    void* out2; int out2_ct, out2_coff;
 };
 
 // First layer (Cin = 3 stored as 4, k=3, s=2): direct convolution.
@@ -119,6 +125,10 @@ hipError_t launch_pool5(Precision p, const PoolArgs& a, hipStream_t s);
 //   so that MFMA row (ni, rr) holds channel 64*blk + 16*(rr>>2) + 4*ni + (rr&3).
 size_t packed_weight_bytes(Precision p, int cout, int cin, int k, int chunk_bytes = 128);
 void pack_weights(Precision p, const float* W, int cout, int cin, int k, void* dst, int chunk_bytes = 128);
+// second layer of a back-to-back pair (ConvArgs::wgt2): [cout2][cin2] 1x1 weights, cin2 = 256, packed like pack_weights(PREC_F16, ...,
+// k = 1) with input channel 64 c + 16 q + 8 kk + j stored at K position 64 c + 32 kk + 8 q + j (what lane quarter q of the first
+// layer's accumulators holds, in the order the MFMA B operand wants it)
+void pack_weights_fused2(const float* W2, int cout2, int cin2, void* dst);
 // fp16x3 context: scaled [hi | lo | hi] passes (each pass padded to whole K chunks); oscale: [pad128(cout)] floats, 2^-s per channel.
 // passes = 2: [w16 | w16] of a filter that is exactly fp16 values times a per-channel scale (oscale = scale); x3_passes() tells which
 // form a layer admits (scale: [cout] or null = ones).

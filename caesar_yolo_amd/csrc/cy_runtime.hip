@@ -14,6 +14,7 @@ using namespace cy;
 
 struct DevConv { void* w = nullptr; float* bias = nullptr; size_t wbytes = 0; float* stem_w = nullptr; void* w32 = nullptr; size_t w32bytes = 0;
                  float* oscale = nullptr;       // fp16x3 context: 2^-e per output channel (undoes the weight scale in the epilogue)
+                 void* w2f = nullptr; size_t w2fbytes = 0;   // on the SECOND layer of a back-to-back pair: its weights in the first layer's accumulator order (pack_weights_fused2)
                  int passes = 3;                // fp16x3 context: passes over K -- 3, or 2 when the filter is fp16-exact up to a per-channel scale (then oscale = that scale)
                  float* dw_w = nullptr;         // dw_w: depth-wise 3x3 weights [9][C] fp32 (YOLO11)
                  void* bneck = nullptr; };      // on a bottleneck's cv1: register-fragment weights of the fused cv1+cv2 kernel (bneck64.hip)
@@ -57,6 +58,7 @@ struct cy_ctx {
     bool profiling = false;
     bool split_last = false;                             // the last forward ran as two half-batches (debug reads see only one)
     bool stem_fused_last = false;                        // the last forward ran model.0 + model.1 as one kernel (no model.0 tensor)
+    int pw_fused_conv = -1;                              // the last forward ran this conv + the 1x1 behind it as one kernel (its tensor was not written)
     bool bneck_fused_last = false;                       // ... and 64-channel bottlenecks as one kernel each (their cv1 outputs do not exist)
     int prof_stride = 1; unsigned long fwd_calls = 0;   // profiling on: every prof_stride-th cy_forward call is timed
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
@@ -88,7 +90,7 @@ size_t tensor_elems_per_tile(const Plan& p, int H, int W) {
 void free_all(cy_ctx* c) {
     for (auto e : c->ev_pool) hipEventDestroy(e);
     c->ev_pool.clear(); c->ev_used = 0; c->prof.clear();
-    for (auto& d : c->dconv) { if (d.w) hipFree(d.w); if (d.bias) hipFree(d.bias); if (d.stem_w) hipFree(d.stem_w); if (d.w32) hipFree(d.w32); if (d.dw_w) hipFree(d.dw_w); if (d.bneck) hipFree(d.bneck); if (d.oscale) hipFree(d.oscale); }
+    for (auto& d : c->dconv) { if (d.w) hipFree(d.w); if (d.bias) hipFree(d.bias); if (d.stem_w) hipFree(d.stem_w); if (d.w32) hipFree(d.w32); if (d.dw_w) hipFree(d.dw_w); if (d.bneck) hipFree(d.bneck); if (d.oscale) hipFree(d.oscale); if (d.w2f) hipFree(d.w2f); }
     c->dconv.clear();
     if (c->ws) hipFree(c->ws);
     c->ws = nullptr;
@@ -176,6 +178,29 @@ bool bneck_pair(const Plan& p, size_t i) {
         if (q.in0 == o.out || q.in1 == o.out || q.res == o.out) return false;
         if (q.out == o.out) return q.out_coff == o.out_coff && q.conv >= 0 && p.convs[q.conv].cout == 64;
     }
+    return true;
+}
+
+// ops[i] = a convolution whose 256 output channels all sit in one tile of the pixels-direct kernel (3x3 stride 2 or 1x1, SiLU, no
+// residual, one input segment), ops[i+1] = the 1x1 convolution (256 -> <= 256 channels, one input segment, no residual) that is the ONLY
+// reader of its output: in the fp16 context the pair runs as one kernel, the first layer's accumulators feeding the second GEMM in
+// registers (conv1x1_direct_kernel<..., FUSE2>; yolov8l: model.3 -> model.4.cv1).  CY_FUSE_PW=0 turns it off.
+bool pw_pair(const Plan& p, size_t i) {
+    if (i + 1 >= p.ops.size()) return false;
+    const Op& o = p.ops[i]; const Op& n = p.ops[i + 1];
+    if (o.kind != OPK_CONV || n.kind != OPK_CONV || o.conv < 0 || n.conv < 0 || o.out < 0 || n.out < 0) return false;
+    const ConvDesc& d1 = p.convs[o.conv]; const ConvDesc& d2 = p.convs[n.conv];
+    if (d1.groups != 1 || d2.groups != 1 || d1.cout != 256 || !d1.act || d1.cin % 64) return false;
+    if (!((d1.k == 3 && d1.s == 2 && d1.cin >= 128) || (d1.k == 1 && d1.s == 1))) return false;
+    if (d2.k != 1 || d2.s != 1 || d2.cin != 256 || d2.cout > 256 || d2.cout % 16) return false;
+    if (o.in1 >= 0 || o.up0 || o.res >= 0 || n.in1 >= 0 || n.up0 || n.res >= 0 || n.c0 != 256) return false;
+    if (n.in0 != o.out || n.in0_coff != o.out_coff || p.tensors[o.out].level != p.tensors[n.out].level) return false;
+    if (n.out == o.out) return false;
+    int readers = 0;                                         // nothing else may read the first layer's output slice
+    for (const Op& q : p.ops) readers += (q.in0 == o.out) + (q.in1 == o.out) + (q.res == o.out);
+    if (readers != 1) return false;
+    for (size_t j = i + 2; j < p.ops.size(); ++j)            // (a later op may overwrite that tensor; none may read it first: counted above)
+        if (p.ops[j].out == o.out) break;
     return true;
 }
 
@@ -353,6 +378,17 @@ int upload_weights(cy_ctx* c, const void* buf, size_t nbytes) {
         if (!bad.empty()) { free_all(c); return fail(c, CY_ERR_IO, "malformed CYW2 plan: " + bad); }
     }
     if (c->prec == PREC_F16) {
+        for (size_t i = 0; i + 1 < plan.ops.size(); ++i) {      // back-to-back pairs: the second layer's weights in accumulator order
+            if (!pw_pair(plan, i)) continue;
+            const int c2 = plan.ops[i + 1].conv;
+            const ConvDesc& d2 = plan.convs[c2];
+            DevConv& dc2 = c->dconv[c2];
+            dc2.w2fbytes = packed_weight_bytes(PREC_F16, d2.cout, d2.cin, 1);
+            std::vector<char> pk(dc2.w2fbytes);
+            pack_weights_fused2(Wsrc[c2], d2.cout, d2.cin, pk.data());
+            HIPCHK(c, hipMalloc(&dc2.w2f, dc2.w2fbytes));
+            HIPCHK(c, hipMemcpy(dc2.w2f, pk.data(), dc2.w2fbytes, hipMemcpyHostToDevice));
+        }
         std::vector<char> wf(BNECK_WFRAG_BYTES);
         for (size_t i = 0; i + 1 < plan.ops.size(); ++i) {
             if (!bneck_pair(plan, i)) continue;
@@ -657,6 +693,8 @@ static int forward_on(cy_ctx* c, const void* d_netin, int B, int H, int W, float
         return readers == 1;
     };
     c->stem_fused_last = false;
+    c->pw_fused_conv = -1;
+    const int pw_env = env_knob("CY_FUSE_PW", 1);             // back-to-back pairs (pw_pair); read per call: the parity tests run both forms
 
     const int bneck_env = env_knob("CY_BNECK_FUSE", 0);       // off by default (slower than two launches so far, see bneck64.hip); read per call: the parity tests run both forms
     auto run_op = [&](const Op& o, const Op* next, int b0, int Bn, bool* fused) -> int {
@@ -768,8 +806,20 @@ static int forward_on(cy_ctx* c, const void* d_netin, int B, int H, int W, float
                 a.out = d_pred; a.out_ct = 64 + p.nc; a.out_coff = o.pred_coff; a.out_bs = A; a.out_ro = a_off[o.pred_level]; a.out_f32 = 1;
             }
             if (o.res >= 0) { a.res = tp(o.res); a.res_ct = cm * p.tensors[o.res].C; a.res_coff = o.res_coff; a.res_lo = p.tensors[o.res].C; }
+            double flops = 2.0 * Bn * a.Ho * a.Wo * (double)a.Cout * a.Cin * a.k * a.k;
+            if (pw_env && c->prec == PREC_F16 && next && next->conv >= 0 && c->dconv[next->conv].w2f && conv_variant(c->prec, a) == CONV_DIRECT_256 &&
+                pw_pair(p, (size_t)(&o - p.ops.data()))) {
+                const Op& n = *next;
+                const ConvDesc& d2 = p.convs[n.conv];
+                const Tensor& to2 = p.tensors[n.out];
+                a.wgt2 = c->dconv[n.conv].w2f; a.wgt2_bytes = (uint32_t)c->dconv[n.conv].w2fbytes; a.bias2 = c->dconv[n.conv].bias;
+                a.act2 = d2.act; a.cout2 = d2.cout;
+                a.out2 = tp(n.out); a.out2_ct = to2.C; a.out2_coff = n.out_coff;
+                flops += 2.0 * Bn * a.Ho * a.Wo * (double)d2.cout * d2.cin;
+                *fused = true; c->pw_fused_conv = o.conv;
+            }
             HIPCHK(c, launch_conv(c->prec, a, s));
-            prof_done(conv_variant(c->prec, a), 2.0 * Bn * a.Ho * a.Wo * (double)a.Cout * a.Cin * a.k * a.k);
+            prof_done(conv_variant(c->prec, a), flops);
         }
         return CY_OK;
     };
@@ -848,6 +898,8 @@ int cy_debug_read_conv(cy_ctx* c, const char* conv_name, float* h_out, size_t ca
         if (o.out < 0) return fail(c, CY_ERR_UNSUPPORTED, "head outputs are read from d_pred");
         if (c->bneck_fused_last && c->dconv[o.conv].bneck && env_knob("CY_BNECK_FUSE", 0))
             return fail(c, CY_ERR_STATE, "this bottleneck ran fused: its cv1 output was not materialised; unset CY_BNECK_FUSE");
+        if (o.conv == c->pw_fused_conv && c->pw_fused_conv >= 0 && env_knob("CY_FUSE_PW", 1))
+            return fail(c, CY_ERR_STATE, "this layer ran fused with the 1x1 convolution behind it: its output was not materialised; CY_FUSE_PW=0 runs the two layers apart");
         if (o.kind == OPK_STEM && c->stem_fused_last)
             return fail(c, CY_ERR_STATE, "the stem output was not materialised (fused into the next layer's kernel); set CY_STEM_FUSE=0");
         const Tensor& t = p.tensors[o.out];

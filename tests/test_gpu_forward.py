@@ -45,6 +45,8 @@ TAPS = ["model.0", "model.1", "model.2.cv1", "model.2.m.2.cv1", "model.12.m.0.cv
     ("fp16", 6e-2, 3e-2, {"CY_STEM_FUSE": "2"}),
     # the 64-channel bottlenecks of model.2 as ONE kernel each (cv1's output stays in LDS; opt-in, default is two launches)
     ("fp16", 6e-2, 3e-2, {"CY_BNECK_FUSE": "1"}),
+    # the back-to-back pair model.3 -> model.4.cv1 as two launches (default: one kernel, the 256-channel map between them never stored)
+    ("fp16", 6e-2, 3e-2, {"CY_FUSE_PW": "0"}),
     # kernel selection that sees the real batch of 2 (the default evaluates every threshold as for 256 tiles)
     ("fp16", 6e-2, 3e-2, {"CY_BATCH_INVARIANT": "0"}), ("fp16", 6e-2, 3e-2, {"CY_BATCH_INVARIANT": "0", "CY_DIRECT_MIN_BLOCKS": "1"})])
 def test_forward_matches_oracle(prec, tol_raw, tol_tap, env, monkeypatch):
@@ -183,6 +185,34 @@ def test_fp16x3_results_do_not_depend_on_the_batch():
     for i in range(4):
         p1 = det.forward(xin[i:i + 1].contiguous()).cpu()
         assert torch.equal(p1[0], p4[i]), "tile %d differs between batch 1 and batch 4" % i
+
+
+def test_back_to_back_pair_runs_in_one_kernel(monkeypatch):
+    """Round 4 layer fusion: model.3 (3x3 s2, 128 -> 256) and its only reader model.4.cv1 (1x1, 256 -> 256) as ONE launch of the
+    pixels-direct kernel -- the first layer's accumulators (bias + SiLU, rounded to fp16 as the store would) are the B operand of the
+    second GEMM in registers.  Against the two-launch form: model.4.cv1's output agrees to fp16 rounding (the second GEMM sums its K in a
+    permuted order), both agree with the oracle, the fused run does not materialise model.3 (debug read refused), head output within 6e-2."""
+    det = detector("fp16")
+    imgs = [_tile("big512", 256, 256), _tile("big512", 256, 256)[:, ::-1].copy()]
+    x, raw, taps = _oracle_forward(imgs, 256)
+    xin = netin_from_chw(x, det.dtype)
+    ref = taps["model.4.cv1"]
+    monkeypatch.setenv("CY_FUSE_PW", "0")
+    p0 = det.forward(xin).cpu()
+    t0 = torch.from_numpy(det.read_conv("model.4.cv1", ref.numel()))
+    m3 = torch.from_numpy(det.read_conv("model.3", taps["model.3"].numel()))
+    assert float((m3 - taps["model.3"]).abs().max()) <= 3e-2 * max(1.0, float(taps["model.3"].abs().max()))
+    monkeypatch.setenv("CY_FUSE_PW", "1")
+    p1 = det.forward(xin).cpu()
+    t1 = torch.from_numpy(det.read_conv("model.4.cv1", ref.numel()))
+    with pytest.raises(Exception, match="not materialised"):
+        det.read_conv("model.3", taps["model.3"].numel())
+    sc = max(1.0, float(ref.abs().max()))
+    d01, e0, e1 = float((t1 - t0).abs().max()), float((t0 - ref).abs().max()), float((t1 - ref).abs().max())
+    print("model.4.cv1: fused vs two launches %.3e, vs oracle %.3e (two launches) / %.3e (fused), scale %.2f; head output fused vs oracle %.3e"
+          % (d01, e0, e1, sc, float((p1 - raw).abs().max())))
+    assert d01 <= 4e-3 * sc and e0 <= 3e-2 * sc and e1 <= 3e-2 * sc
+    assert float((p1 - raw).abs().max()) <= 6e-2 * max(1.0, float(raw.abs().max())) and float((p0 - raw).abs().max()) <= 6e-2 * max(1.0, float(raw.abs().max()))
 
 
 def test_fp16x3_two_pass_form_on_fp16_checkpoints(monkeypatch):
