@@ -30,6 +30,17 @@ from .preprocessing import no_preprocessing
 logger = logging.getLogger("caesar_yolo_amd")
 
 
+def wcs_of_header(header):
+    """The `WCS(header)` of caesar_yolo/inference.py:473 (and utils.py:234-238, where a failure is logged and the WCS dropped):
+    caesar_yolo_amd.wcs restates the celestial part of the standard; nothing on the detect path reads it."""
+    from .wcs import WCS
+    try:
+        return WCS(header)
+    except Exception as e:
+        logger.warning("Failed to get wcs from header (err=%s)!" % str(e))
+        return None
+
+
 def shard(items, rank, world):
     """Contiguous chunk `rank` of `world` (sizes differ by at most one)."""
     n = len(items)
@@ -434,6 +445,7 @@ class SFinder(object):
         """Beam / pixel metadata of the reference's read_img (caesar_yolo/inference.py:430-468): beamArea = pi*BMAJ*BMIN /
         (4 ln 2) / |CDELT1*CDELT2| pixels, 0 when any of the five keywords is missing (a warning per keyword, as there)."""
         h = self.header
+        self.wcs = wcs_of_header(h)                       # caesar_yolo/inference.py:473
         self.beamArea, ok = 0, True
         for key, attr in (("CDELT1", "dX"), ("CDELT2", "dY"), ("BMAJ", "bmaj"), ("BMIN", "bmin"), ("BPA", "pa")):
             if key not in h:

@@ -642,11 +642,58 @@ def run_tiled(outdir, scratch, tag, nx, ny, tsize, step, seed, nper=10, dense=Fa
         sum(1 for s in json.loads(cat_text)["sources"] if s["merged"])))
 
 
+def gen_wcs(outdir):
+    """World coordinates of astropy.wcs.WCS(header) -- what the reference builds at inference.py:473 / utils.py:236, :411 -- for the
+    header kinds its inputs carry (radio mosaics: SIN / TAN equatorial, CAR galactic; CD / PC / CROTA2 conventions; no WCS at all
+    like test/galaxy0001.fits): pixel -> world and back at seeded pixel positions, both origins."""
+    import warnings
+    warnings.filterwarnings("ignore")
+    from astropy.wcs import WCS as AW
+    headers = {
+        "tan": dict(CTYPE1="RA---TAN", CTYPE2="DEC--TAN", CRPIX1=500.5, CRPIX2=400.5, CRVAL1=266.4, CRVAL2=-28.9, CDELT1=-0.000555, CDELT2=0.000555),
+        "sin": dict(CTYPE1="RA---SIN", CTYPE2="DEC--SIN", CRPIX1=321.0, CRPIX2=123.0, CRVAL1=12.5, CRVAL2=-45.0, CDELT1=-0.001, CDELT2=0.001),
+        "car_gal": dict(CTYPE1="GLON-CAR", CTYPE2="GLAT-CAR", CRPIX1=2000.0, CRPIX2=300.0, CRVAL1=5.5, CRVAL2=0.0, CDELT1=-0.0016667, CDELT2=0.0016667),
+        "car_off": dict(CTYPE1="GLON-CAR", CTYPE2="GLAT-CAR", CRPIX1=100.0, CRPIX2=50.0, CRVAL1=340.0, CRVAL2=1.5, CDELT1=-0.002, CDELT2=0.002),
+        "tan_cd": dict(CTYPE1="RA---TAN", CTYPE2="DEC--TAN", CRPIX1=10.0, CRPIX2=20.0, CRVAL1=83.6, CRVAL2=22.0, CD1_1=-0.0004, CD1_2=0.0001, CD2_1=0.0001, CD2_2=0.0004),
+        "tan_pc": dict(CTYPE1="RA---TAN", CTYPE2="DEC--TAN", CRPIX1=256.0, CRPIX2=256.0, CRVAL1=201.3, CRVAL2=-43.0, CDELT1=-0.0008, CDELT2=0.0008,
+                       PC1_1=0.9, PC1_2=-0.43589, PC2_1=0.43589, PC2_2=0.9),
+        "sin_rot": dict(CTYPE1="RA---SIN", CTYPE2="DEC--SIN", CRPIX1=512.0, CRPIX2=512.0, CRVAL1=0.2, CRVAL2=70.0, CDELT1=-0.0011, CDELT2=0.0011, CROTA2=15.0),
+        "tan_lonpole": dict(CTYPE1="RA---TAN", CTYPE2="DEC--TAN", CRPIX1=50.0, CRPIX2=60.0, CRVAL1=150.0, CRVAL2=2.2, CDELT1=-0.0005, CDELT2=0.0005, LONPOLE=170.0),
+        "sfl": dict(CTYPE1="GLON-SFL", CTYPE2="GLAT-SFL", CRPIX1=300.0, CRPIX2=200.0, CRVAL1=30.0, CRVAL2=0.0, CDELT1=-0.003, CDELT2=0.003),
+        "arc": dict(CTYPE1="RA---ARC", CTYPE2="DEC--ARC", CRPIX1=30.0, CRPIX2=20.0, CRVAL1=45.0, CRVAL2=-10.0, CDELT1=-0.01, CDELT2=0.01),
+        "linear": dict(CRPIX1=1.0, CRPIX2=1.0, CRVAL1=0.0, CRVAL2=0.0, CDELT1=1.0, CDELT2=1.0),
+        "galaxy0001_like": dict(BMAJ=0.00416, BMIN=0.00416, BPA=0.0),           # no WCS keywords at all (test/galaxy0001.fits)
+    }
+    rng = np.random.default_rng(404)
+    out = {}
+    for name, kw in headers.items():
+        h = _afits.Header()
+        h["NAXIS"] = 2; h["NAXIS1"] = 1000; h["NAXIS2"] = 800
+        for k, v in kw.items():
+            h[k] = v
+        w = AW(h)
+        x, y = rng.uniform(-50, 1200, 24), rng.uniform(-50, 900, 24)
+        rec = {"header": {k: (v if not isinstance(v, (np.floating, np.integer)) else v.item()) for k, v in kw.items()}, "x": x.tolist(), "y": y.tolist()}
+        for origin in (0, 1):
+            a, d = w.all_pix2world(x, y, origin)
+            px, py = w.wcs_world2pix(a, d, origin)
+            rec["world_%d" % origin] = [np.asarray(a).tolist(), np.asarray(d).tolist()]
+            rec["pix_back_%d" % origin] = [np.asarray(px).tolist(), np.asarray(py).tolist()]
+        rec["pixel_scale_matrix"] = np.asarray(w.pixel_scale_matrix).tolist()
+        out[name] = rec
+    with open(os.path.join(outdir, "wcs.json"), "w") as fp:
+        json.dump(out, fp)
+    print("wcs.json: %d headers (astropy %s)" % (len(out), __import__("astropy").__version__))
+
+
 def main():
     outdir = sys.argv[1] if len(sys.argv) > 1 else "/root/repo/tests/golden"
     scratch = "/tmp/caesar_golden_scratch"
     os.makedirs(scratch, exist_ok=True)
     os.makedirs(outdir, exist_ok=True)
+    if len(sys.argv) > 2 and sys.argv[2] == "round4":      # additions of round 4 only: world coordinates of astropy.wcs.WCS(header)
+        gen_wcs(outdir)
+        return
     if len(sys.argv) > 2 and sys.argv[2] == "round2":      # additions of round 2 only (the other fixtures stay byte-identical)
         gen_preproc_chid(outdir)
         run_tiled(outdir, scratch, "d", 1500, 1100, 256, 0.5, 34, nper=2, dense=True, save_img=False)
@@ -660,6 +707,7 @@ def main():
     run_tiled(outdir, scratch, "c", 900, 700, 256, 0.5, 33, nper=6)
     gen_preproc_chid(outdir)
     run_tiled(outdir, scratch, "d", 1500, 1100, 256, 0.5, 34, nper=2, dense=True, save_img=False)
+    gen_wcs(outdir)
 
 
 if __name__ == "__main__":
