@@ -201,6 +201,7 @@ struct PreArgs {
     double* scratch;                       // [B][3][th*tw] fp64 preprocessed image when a resize is needed, else null
     int new_h, new_w;                      // resized size (== th,tw when no resize)
     int* counters;                         // context counters or null: [2] += median-bracket hits, [3] += misses (cy_preproc.hip)
+    int variant;                           // developer A/B switch of the statistics kernel (CY_PRE_VARIANT; 0 = shipped form)
 };
 hipError_t launch_preproc(const PreArgs& a, hipStream_t s);
 hipError_t launch_preproc_planes(const PreArgs& a, hipStream_t s);    // statistics + checks + float64 planes into a.scratch (no packing)

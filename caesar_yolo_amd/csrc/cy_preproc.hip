@@ -26,6 +26,7 @@
 #include "cy_kernels.h"
 #include <math.h>
 #include <stddef.h>
+#include <stdlib.h>
 #pragma clang fp contract(off)
 
 namespace cy {
@@ -102,6 +103,7 @@ struct Smem {
     double q0[MAX_STAGES], q1[MAX_STAGES];
     double par[MAX_STAGES * 4];          // ... and the parameters solved so far
     unsigned long long bcu[4];
+    int variant;
     unsigned ncand;                      // raw keys of the set members inside the median bracket of the current pass
     unsigned cand[NCAND];
 };
@@ -273,6 +275,10 @@ __device__ __forceinline__ void set_bounds(ClipSet& cs, double L, double U) {
 // f(raw fp32, value, in_box, ok) is called by every lane of the workgroup (ok = false past the row end / tile end): it may ballot.
 // RAW = true: the stage reads the raw pixels (upto == 0): value = (double)raw, nothing to replay.
 constexpr int PXG = 2;
+#ifndef CY_PXGP
+#define CY_PXGP 2
+#endif
+constexpr int PXGP = CY_PXGP;       // groups per thread and step of the plain raw moments pass
 template <bool RAW, typename F>
 __device__ __forceinline__ void for_pixels(const Smem& s, const TileView& tv, int upto, const ClipSet* box, F&& f) {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -428,7 +434,6 @@ __device__ __forceinline__ void moments_loop(Smem& s, const TileView& tv, int up
     int y = (int)threadIdx.x / GR, gx = (int)threadIdx.x - y * GR;
     const int dy = NT / GR, dx = NT - dy * GR;
     const bool partial = (tv.tw & 3) != 0;                    // the last group of a row reaches past the tile
-    const bool plain = RAW && !partial && !cs.use_box;        // the fast path applies (uniform)
     // The groups of step i + 1 are requested before those of step i are consumed (register double buffer): with the arithmetic of a
     // step down to ~1 us (round 4) the ~2 us a step waited for its own loads were two thirds of a pass.
     f32x4 rn[PXG];
@@ -454,36 +459,7 @@ __device__ __forceinline__ void moments_loop(Smem& s, const TileView& tv, int up
 #pragma unroll
         for (int u = 0; u < PXG; ++u) {
             unsigned inmask = 0u;                                 // MODE >= 2: which of the group's pixels are set members inside the bracket
-            bool fast = false;
-            if (RAW && MODE != 1 && plain) {                  // (MODE 1 keeps the wave convergent around its ballot-aggregated histogram)
-                // all four members: smallest >= Lf, largest <= Uf, none zero (|r| of the smallest magnitude > 0), none NaN (min / max skip a
-                // NaN operand; the sum does not -- buffers that did not go through cy_mosaic_prepare may hold them)
-                const float r0 = r[u][0], r1 = r[u][1], r2 = r[u][2], r3 = r[u][3];
-                const float mn = fminf(fminf(r0, r1), fminf(r2, r3)), mx = fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
-                const float am = fminf(fminf(fabsf(r0), fabsf(r1)), fminf(fabsf(r2), fabsf(r3)));
-                const float t4 = (r0 + r1) + (r2 + r3);
-                fast = mn >= cs.Lf && mx <= cs.Uf && am > 0.0f && t4 == t4;
-                if (fast) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const double d = (double)r[u][e] - K;
-                        s1 += d; s2 += d * d;
-                    }
-                    ucnt += 4u;
-                    if (MODE >= 2) {
-                        if (mx < br.lf) below += 4u;
-                        else if (mn <= br.hf) {                       // the group reaches into (or past) the bracket
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float rf = r[u][e];
-                                inmask |= (rf >= br.lf && rf <= br.hf) ? (1u << e) : 0u;
-                                below += rf < br.lf ? 1u : 0u;
-                            }
-                        }
-                    }
-                }
-            }
-            if (!fast) {
+            {
                 double v[4];
                 bool act[4];
 #pragma unroll
@@ -541,6 +517,96 @@ __device__ __forceinline__ void moments_loop(Smem& s, const TileView& tv, int up
     }
 }
 
+// The same pass for the case nearly every sigma-clip pass of the benchmarks is: a stage that reads the RAW pixels of a tile whose rows are
+// whole groups of four, no masked box, no histogram.  The ISA of the general loop above spends ~40 vector instructions per pixel, most
+// of them on materialising booleans (row-end / box / pass-flag combinations as 0/1 registers) -- a pass of 16 waves over 410k pixels is
+// bound by instruction issue (4 waves per SIMD x ~330 instructions per 8-pixel step), not by the memory path.  Here every test is a
+// compare whose result IS the wave's ballot (an SGPR pair): counts (members, members below the bracket, members inside it) are
+// s_bcnt1 sums in scalar registers, the moments are accumulated under the member mask with one cvt, one subtract, one add and one fma per
+// pixel, and the bracket's members are appended with one LDS atomic per wave and group.  ~12 vector instructions per pixel.
+// MODE 0: count + moments; 2: + members below / inside the bracket counted; 3: + the bracket's members appended to s.cand.
+template <int MODE, int G>
+__device__ __forceinline__ void moments_plain(Smem& s, const TileView& tv, const ClipSet& cs, double K, const Bracket& br,
+                                              double& s1, double& s2, unsigned& ucnt, unsigned& below, unsigned& ucand) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int GR = tv.tw >> 2, NG = tv.th * GR;
+    const int lane = (int)threadIdx.x & 63;
+    const float Lf = cs.Lf, Uf = cs.Uf, blf = br.lf, bhf = br.hf;
+    unsigned wcnt = 0u, wbelow = 0u, wcand = 0u;              // wave-uniform (scalar registers)
+    // byte offset of the thread's next group, advanced by NT groups per load without a multiplication: dy rows and dx groups further, one
+    // more row when the column wraps
+    int gx, g = (int)threadIdx.x;
+    unsigned off;
+    { const int y0 = g / GR; gx = g - y0 * GR; off = (unsigned)(y0 * tv.MW + (gx << 2)) * 4u; }
+    const int dy = NT / GR, dx = NT - dy * GR;
+    const unsigned step_a = (unsigned)(dy * tv.MW + (dx << 2)) * 4u, step_b = step_a + (unsigned)(tv.MW - tv.tw) * 4u;
+    auto request = [&](f32x4 (&dst)[G]) {
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            dst[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(tv.rs, g < NG ? off : 0xFFFFFF00u, 0, 0));   // past the end: zeros = not in any set
+            g += NT; gx += dx;
+            const bool wrap = gx >= GR;
+            gx -= wrap ? GR : 0;
+            off += wrap ? step_b : step_a;
+        }
+    };
+    auto consume = [&](const f32x4 (&r)[G]) {
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            bool in[4] = {false, false, false, false};
+            unsigned long long mc[4] = {0ull, 0ull, 0ull, 0ull};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float rf = r[u][e];
+                const bool a = rf >= Lf && rf <= Uf && rf != 0.0f;         // (NaN fails; +-inf is outside the clamped bounds)
+                // (the ballot of a plain compare IS its result register; the ballot of a combined boolean costs two more vector instructions)
+                const unsigned long long ma = __builtin_amdgcn_ballot_w64(rf >= Lf) & __builtin_amdgcn_ballot_w64(rf <= Uf) & __builtin_amdgcn_ballot_w64(rf != 0.0f);
+                wcnt += (unsigned)__builtin_popcountll(ma);
+                double d = (double)rf - K;
+                d = a ? d : 0.0;
+                s1 += d; s2 = __builtin_fma(d, d, s2);
+                if (MODE >= 2) {
+                    const bool lt = rf < blf, le = rf <= bhf;
+                    const unsigned long long mlt = __builtin_amdgcn_ballot_w64(lt);
+                    wbelow += (unsigned)__builtin_popcountll(ma & mlt);
+                    in[e] = a && !lt && le;
+                    mc[e] = ma & ~mlt & __builtin_amdgcn_ballot_w64(le);
+                    if (MODE == 2) wcand += (unsigned)__builtin_popcountll(mc[e]);
+                }
+            }
+            if (MODE == 3) {
+                if ((mc[0] | mc[1] | mc[2] | mc[3]) != 0ull) {             // wave-uniform
+                    unsigned tot = 0u, my[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {                          // slots: pixel e of all lanes, then pixel e + 1
+                        my[e] = __builtin_amdgcn_mbcnt_hi((unsigned)(mc[e] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mc[e], tot));
+                        tot += (unsigned)__builtin_popcountll(mc[e]);
+                    }
+                    unsigned base = 0u;
+                    if (lane == 0) base = atomicAdd(&s.ncand, tot);
+                    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                    if (base + tot <= (unsigned)NCAND) {                   // (an overflowing bracket is a miss anyway: s.ncand says so)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (in[e]) s.cand[base + my[e]] = fkey(r[u][e]);
+                    }
+                }
+            }
+        }
+    };
+    // two register sets in turn: the groups of the step after next are requested before this step's are consumed, and no set is ever copied
+    f32x4 ra[G], rb[G];
+    request(ra);
+    for (int g0 = 0; g0 < NG; g0 += 2 * G * NT) {
+        const bool more1 = g0 + G * NT < NG, more2 = g0 + 2 * G * NT < NG;
+        if (more1) request(rb);
+        consume(ra);
+        if (more2) request(ra);
+        if (more1) consume(rb);
+    }
+    ucnt = lane == 0 ? wcnt : 0u; below = lane == 0 ? wbelow : 0u; ucand = lane == 0 ? wcand : 0u;
+}
+
 // One pass over the set: count and moments about K; optionally the level-0 radix histogram of the raw keys (s.histA); and,
 // given a bracket [vl, vh] of values around the expected median, the number of members below it and the raw keys of the
 // members inside it (s.cand, up to NCAND), from which the median is then selected without another pass over the tile.
@@ -554,7 +620,19 @@ __device__ __forceinline__ void set_moments(Smem& s, const TileView& tv, int upt
     __syncthreads();
     double s1 = 0.0, s2 = 0.0;
     unsigned below = 0u, ucnt = 0u, ucand = 0u;
-    if (want_hist) moments_loop<RAW, 1>(s, tv, upto, cs, K, br, s1, s2, ucnt, below, ucand);      // (never together with a bracket)
+    bool plain = false;
+    if constexpr (RAW) plain = !want_hist && (tv.tw & 3) == 0 && !cs.use_box;
+    if (plain && (s.variant & 2)) plain = false;
+    if (plain && (s.variant & 1)) {
+        if (!br.on) moments_plain<0, 4>(s, tv, cs, K, br, s1, s2, ucnt, below, ucand);
+        else if (!br.collect) moments_plain<2, 4>(s, tv, cs, K, br, s1, s2, ucnt, below, ucand);
+        else moments_plain<3, 4>(s, tv, cs, K, br, s1, s2, ucnt, below, ucand);
+    } else if (plain) {
+        if (!br.on) moments_plain<0, PXGP>(s, tv, cs, K, br, s1, s2, ucnt, below, ucand);
+        else if (!br.collect) moments_plain<2, PXGP>(s, tv, cs, K, br, s1, s2, ucnt, below, ucand);
+        else moments_plain<3, PXGP>(s, tv, cs, K, br, s1, s2, ucnt, below, ucand);
+    }
+    else if (want_hist) moments_loop<RAW, 1>(s, tv, upto, cs, K, br, s1, s2, ucnt, below, ucand);      // (never together with a bracket)
     else if (!br.on) moments_loop<RAW, 0>(s, tv, upto, cs, K, br, s1, s2, ucnt, below, ucand);
     else if (!br.collect) moments_loop<RAW, 2>(s, tv, upto, cs, K, br, s1, s2, ucnt, below, ucand);
     else moments_loop<RAW, 3>(s, tv, upto, cs, K, br, s1, s2, ucnt, below, ucand);
@@ -842,13 +920,84 @@ __device__ __forceinline__ void histeq_run(Smem& s, const TileView& tv, int upto
     __syncthreads();
 }
 
+// MINMAX behind a chain whose non-zero test is a single threshold on the RAW pixel (round 4): the chains of the benchmarks -- nothing,
+// [ZSCALE], [HISTEQ], [CLIP, ZSCALE] -- keep a pixel exactly when it is non-zero, finite and (ZSCALE last) its value after the clamp
+// exceeds vmin:  clamp(v, lo, hi) - vmin > 0  <=>  v > vmin  when lo <= vmin < hi (always / never on either side of that), and
+// (double)r > T  <=>  r > Tf  with Tf the largest float not above T.  The quotient of the ZSCALE stage cannot underflow to zero for
+// rng <= 1e200 (d is a difference of a float and a double: never below 2^-1074, so d / rng > 0), which nz_test's slow branch guards.
+// -> true and the threshold, or false: the chain is not of that kind (general pass).
+__device__ __forceinline__ bool raw_threshold(const Smem& s, int upto, float* tf) {
+    double T = -INFINITY;
+    double lo = -INFINITY, hi = INFINITY;                         // clamp in front of the last stage (at most one CLIP)
+    for (int k = 0; k < upto; ++k) {
+        const int op = s.op[k];
+        const double* sp = s.par + k * 4;
+        const bool last = k + 1 == upto;
+        if (op == OP_CLIP && !last && k == 0) {
+            lo = sp[0]; hi = sp[1];
+            if (!(lo < 0.0 && hi > 0.0)) return false;             // (a bound at or beyond zero changes which pixels are clamped TO zero)
+        } else if (op == OP_ZSCALE && last) {
+            const double vmin = sp[0], rng = sp[1] - sp[0];
+            if (!(rng >= 0.0) || !(rng <= 1e200) || !isfinite(vmin)) return false;
+            if (vmin < lo) T = -INFINITY;                          // every clamped value is above vmin
+            else if (vmin >= hi) return false;                     // none is: leave it to the general pass
+            else T = vmin;
+        } else if (op == OP_HISTEQ && last && k == 0) {
+            // interpolated cdf of a non-zero finite value: never zero (see chain_nonzero)
+        } else return false;
+    }
+    *tf = T == -INFINITY ? -INFINITY : f_not_above(T);
+    return true;
+}
+// min / max of the raw pixels with r != 0, |r| <= FLT_MAX, r > tf over a tile of whole groups: seven vector instructions per pixel
+__device__ __forceinline__ void minmax_plain(const TileView& tv, float tf, float& rmn, float& rmx) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int GR = tv.tw >> 2, NG = tv.th * GR;
+    int gx, g = (int)threadIdx.x;
+    unsigned off;
+    { const int y0 = g / GR; gx = g - y0 * GR; off = (unsigned)(y0 * tv.MW + (gx << 2)) * 4u; }
+    const int dy = NT / GR, dx = NT - dy * GR;
+    const unsigned step_a = (unsigned)(dy * tv.MW + (dx << 2)) * 4u, step_b = step_a + (unsigned)(tv.MW - tv.tw) * 4u;
+    constexpr int G = 2;
+    auto request = [&](f32x4 (&dst)[G]) {
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            dst[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(tv.rs, g < NG ? off : 0xFFFFFF00u, 0, 0));   // past the end: zeros
+            g += NT; gx += dx;
+            const bool wrap = gx >= GR;
+            gx -= wrap ? GR : 0;
+            off += wrap ? step_b : step_a;
+        }
+    };
+    auto consume = [&](const f32x4 (&r)[G]) {
+#pragma unroll
+        for (int u = 0; u < G; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float rf = r[u][e];
+                const bool a = rf > tf && rf <= 3.402823466e+38f && rf != 0.0f;      // (NaN fails)
+                rmn = (a && rf < rmn) ? rf : rmn;
+                rmx = (a && rf > rmx) ? rf : rmx;
+            }
+    };
+    f32x4 ra[G], rb[G];
+    request(ra);
+    for (int g0 = 0; g0 < NG; g0 += 2 * G * NT) {
+        const bool more1 = g0 + G * NT < NG, more2 = g0 + 2 * G * NT < NG;
+        if (more1) request(rb);
+        consume(ra);
+        if (more2) request(ra);
+        if (more1) consume(rb);
+    }
+}
+
 // ---------------------------------------------------------------------------------------- statistics kernel
 // The argument block is read through scalar fields and two copies into LDS only (the channel's program, the tile origin):
 // handing `a.prog[p]` to the routines above by reference made the compiler keep a private copy of the whole 3.3 KB block in
 // scratch memory (ScratchSize 3352 B per lane, ~570 MB of scratch writes per launch) and read every stage from there per pixel.
 __global__ __launch_bounds__(NT) void pre_stats_kernel(const PreArgs a) {
     __shared__ Smem s;
-    const int b = blockIdx.x, p = blockIdx.y;
+    const int b = blockIdx.x % a.B, p = blockIdx.x / a.B;      // program-major: the long sigma-clip programs first, the short HISTEQ one last
     // dynamically indexed members (prog[p].st[k], txy[2b]) are read straight from the kernel-argument segment
     typedef const __attribute__((address_space(4))) char* kptr;
     const kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -856,6 +1005,7 @@ __global__ __launch_bounds__(NT) void pre_stats_kernel(const PreArgs a) {
     auto kint = [](kptr q) { return *(const __attribute__((address_space(4))) int*)q; };
     auto kdbl = [](kptr q) { return *(const __attribute__((address_space(4))) double*)q; };
     const int nst = kint(kprog + offsetof(PreProgram, n));
+    if (threadIdx.x == 0) s.variant = a.variant;
     if (threadIdx.x < MAX_STAGES) {
         const int k = threadIdx.x;
         const kptr ks = kprog + offsetof(PreProgram, st) + (size_t)k * sizeof(PreStage);
@@ -905,7 +1055,10 @@ __global__ __launch_bounds__(NT) void pre_stats_kernel(const PreArgs a) {
             if (increasing) {
                 float rmn = INFINITY, rmx = -INFINITY;
                 const NzChain nz = nz_chain(s, k);
-                if (nz.ok) {
+                float tf = 0.0f;
+                if ((tv.tw & 3) == 0 && !(s.variant & 4) && raw_threshold(s, k, &tf)) {
+                    minmax_plain(tv, tf, rmn, rmx);
+                } else if (nz.ok) {
                     for_pixels<true>(s, tv, k, nullptr, [&](float rf, double, bool, bool ok) {
                         if (ok && nz_test(nz, rf)) { rmn = fminf(rmn, rf); rmx = fmaxf(rmx, rf); }
                     });
@@ -1052,10 +1205,13 @@ __global__ __launch_bounds__(256) void pre_rowcheck_kernel(const PreArgs a) {
     if (threadIdx.x == 0 && bad && a.status[b] == 0) a.status[b] = 2;
 }
 
-hipError_t launch_preproc(const PreArgs& a, hipStream_t s) {
+static int pre_variant() { static const int v = getenv("CY_PRE_VARIANT") ? atoi(getenv("CY_PRE_VARIANT")) : 0; return v; }
+
+hipError_t launch_preproc(const PreArgs& a0, hipStream_t s) {
+    PreArgs a = a0; a.variant = pre_variant();
     hipError_t e = hipMemsetAsync(a.status, 0, a.B * sizeof(int), s);
     if (e != hipSuccess) return e;
-    if (a.nprog > 0) hipLaunchKernelGGL(pre_stats_kernel, dim3(a.B, a.nprog), dim3(NT), 0, s, a);
+    if (a.nprog > 0) hipLaunchKernelGGL(pre_stats_kernel, dim3(a.B * a.nprog), dim3(NT), 0, s, a);
     hipLaunchKernelGGL(pre_rowcheck_kernel, dim3(a.B), dim3(256), 0, s, a);
     const int npx = a.H * a.W;
     int gx = (npx + 255) / 256; if (gx > 1024) gx = 1024;
@@ -1073,10 +1229,11 @@ hipError_t launch_preproc(const PreArgs& a, hipStream_t s) {
 
 // statistics + rejection checks + the preprocessed image itself as float64 planes [B][3][th*tw] in a.scratch (what
 // DataPreprocessor returns to Analyzer.predict, caesar_yolo/evaluation.py:157-161): parity witness and the plotting input
-hipError_t launch_preproc_planes(const PreArgs& a, hipStream_t s) {
+hipError_t launch_preproc_planes(const PreArgs& a0, hipStream_t s) {
+    PreArgs a = a0; a.variant = pre_variant();
     hipError_t e = hipMemsetAsync(a.status, 0, a.B * sizeof(int), s);
     if (e != hipSuccess) return e;
-    if (a.nprog > 0) hipLaunchKernelGGL(pre_stats_kernel, dim3(a.B, a.nprog), dim3(NT), 0, s, a);
+    if (a.nprog > 0) hipLaunchKernelGGL(pre_stats_kernel, dim3(a.B * a.nprog), dim3(NT), 0, s, a);
     hipLaunchKernelGGL(pre_rowcheck_kernel, dim3(a.B), dim3(256), 0, s, a);
     int gs = (a.th * a.tw + 255) / 256; if (gs > 1024) gs = 1024;
     hipLaunchKernelGGL(pre_plane_kernel, dim3(gs, a.B), dim3(256), 0, s, a);

@@ -435,7 +435,9 @@ int upload_weights(cy_ctx* c, const void* buf, size_t nbytes) {
     HIPCHK(c, hipMalloc(&c->counters, 4 * sizeof(int)));
     HIPCHK(c, hipMemset(c->counters, 0, 4 * sizeof(int)));
     // side streams at the LOWEST priority: preprocessing and decode/NMS/merge fill the gaps of the conv stack on the caller's
-    // stream instead of competing with it for CUs (CY_SIDE_PRIO=0 restores default-priority streams)
+    // stream instead of competing with it for CUs (CY_SIDE_PRIO=0 restores default-priority streams).  Round 4: confining them to a
+    // subset of the CUs instead (hipExtStreamCreateWithCUMask, 64 / 32 / 16 CUs spread over the XCDs) costs 10-12 % of the S16k rate
+    // (8950 -> 8000 / 8000 / 7910 tiles/s): the pass then waits for its side kernels.
     int prio_lo = 0, prio_hi = 0;
     hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);          // lo = numerically greatest = lowest priority
     const bool low = !(getenv("CY_SIDE_PRIO") && atoi(getenv("CY_SIDE_PRIO")) == 0);

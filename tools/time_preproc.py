@@ -20,6 +20,9 @@ specs["bkg"] = [("bkg", dict(sigma=3))]
 specs["zscale"] = [("zscale", dict(contrasts=[0.25] * 3))]
 specs["minmax"] = [("minmax", dict(norm_min=0, norm_max=255))]
 specs["none"] = []
+specs["clip3z"] = [("clip", dict(sigma_low=0, sigma_up=10)), ("zscale", dict(contrasts=[0.25] * 3))]
+specs["clip3zm"] = specs["clip3z"] + [("minmax", dict(norm_min=0, norm_max=255))]
+specs["chan3"] = specs["chan3+minmax"][:2]
 n = 8192
 m = YOLO("seeded:n:5", precision="fp16", max_batch=B, max_imgsz=tile, device=0)
 det = m.engine(0)
