@@ -909,46 +909,6 @@ __device__ __forceinline__ void zscale_run(Smem& s, const TileView& tv, int upto
     __syncthreads();
 }
 
-// skimage equalize_hist tables: np.histogram(image, 256) over [min,max] (zeros included), cdf, bin centres
-__device__ __forceinline__ void histeq_run(Smem& s, const TileView& tv, int upto, double* heq_global) {
-    double mn = INFINITY, mx = -INFINITY;
-    for_pixels<false>(s, tv, upto, nullptr, [&](float, double v, bool, bool ok) {
-        if (ok) { mn = fmin(mn, v); mx = fmax(mx, v); }
-    });
-    mn = block_min(s, mn); mx = block_max(s, mx);
-    double first = mn, last = mx;
-    if (first == last) { first -= 0.5; last += 0.5; }
-    const double step = (last - first) / 256.0;
-    auto edge = [&](int i) { return i == 256 ? last : (double)i * step + first; };       // np.linspace
-    __syncthreads();
-    clear_hists(s, false);
-    __syncthreads();
-    for_pixels<false>(s, tv, upto, nullptr, [&](float, double v, bool, bool act) {
-        int idx = 0;
-        if (act) {
-            idx = (int)(((v - first) / (last - first)) * 256.0);
-            if (idx == 256) idx = 255;
-            if (idx < 0) idx = 0;
-            if (idx > 255) idx = 255;
-            if (v < edge(idx)) idx -= 1;
-            else if (v >= edge(idx + 1) && idx != 255) idx += 1;
-        }
-        hist_add(s.histA, (unsigned)idx, act);
-    });
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long c = 0ull;
-        for (int i = 0; i < 256; ++i) { c += s.histA[i]; s.zs[i] = (double)c; }
-        for (int i = 0; i < 256; ++i) {
-            s.heq[256 + i] = s.zs[i] / (double)c;
-            s.heq[i] = (edge(i) + edge(i + 1)) / 2.0;
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 512; i += NT) heq_global[i] = s.heq[i];
-    __syncthreads();
-}
-
 // MINMAX behind a chain whose non-zero test is a single threshold on the RAW pixel (round 4): the chains of the benchmarks -- nothing,
 // [ZSCALE], [HISTEQ], [CLIP, ZSCALE] -- keep a pixel exactly when it is non-zero, finite and (ZSCALE last) its value after the clamp
 // exceeds vmin:  clamp(v, lo, hi) - vmin > 0  <=>  v > vmin  when lo <= vmin < hi (always / never on either side of that), and
@@ -979,6 +939,8 @@ __device__ __forceinline__ bool raw_threshold(const Smem& s, int upto, float* tf
     return true;
 }
 // min / max of the raw pixels with r != 0, |r| <= FLT_MAX, r > tf over a tile of whole groups: seven vector instructions per pixel
+// ALL = true: every pixel of the tile counts, zeros included (the range of a HISTEQ stage); a NaN fails both compares
+template <bool ALL = false>
 __device__ __forceinline__ void minmax_plain(const TileView& tv, float tf, float& rmn, float& rmx) {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const int GR = tv.tw >> 2, NG = tv.th * GR;
@@ -1004,7 +966,7 @@ __device__ __forceinline__ void minmax_plain(const TileView& tv, float tf, float
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float rf = r[u][e];
-                const bool a = rf > tf && rf <= 3.402823466e+38f && rf != 0.0f;      // (NaN fails)
+                const bool a = ALL || (rf > tf && rf <= 3.402823466e+38f && rf != 0.0f);      // (NaN fails)
                 rmn = (a && rf < rmn) ? rf : rmn;
                 rmx = (a && rf > rmx) ? rf : rmx;
             }
@@ -1018,6 +980,122 @@ __device__ __forceinline__ void minmax_plain(const TileView& tv, float tf, float
         if (more2) request(ra);
         if (more1) consume(rb);
     }
+}
+
+// Histogram pass of a HISTEQ stage that reads the raw pixels, over a tile of whole groups with no group past its end (round 4): the
+// bin of a pixel is a non-decreasing function of the pixel (the float64 quotient is, and numpy's one-step correction against the bin
+// edges keeps it so), hence bin(r) = number of i in 1..255 with r >= thr[i], thr[i] = the smallest float whose bin is >= i (found once
+// per tile by bisection over the float keys with the exact float64 formula).  Per pixel: a float32 guess, a walk along thr (zero or one
+// step) and the aggregated increment -- instead of a float64 division, two edge evaluations and their compares.
+__device__ __forceinline__ void hist_plain(const TileView& tv, const float* thr, float firstf, float invf, unsigned* hist) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int GR = tv.tw >> 2, NG = tv.th * GR;
+    int gx, g = (int)threadIdx.x;
+    unsigned off;
+    { const int y0 = g / GR; gx = g - y0 * GR; off = (unsigned)(y0 * tv.MW + (gx << 2)) * 4u; }
+    const int dy = NT / GR, dx = NT - dy * GR;
+    const unsigned step_a = (unsigned)(dy * tv.MW + (dx << 2)) * 4u, step_b = step_a + (unsigned)(tv.MW - tv.tw) * 4u;
+    constexpr int G = 2;
+    auto request = [&](f32x4 (&dst)[G]) {
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            dst[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(tv.rs, off, 0, 0));
+            g += NT; gx += dx;
+            const bool wrap = gx >= GR;
+            gx -= wrap ? GR : 0;
+            off += wrap ? step_b : step_a;
+        }
+    };
+    auto consume = [&](const f32x4 (&r)[G]) {
+#pragma unroll
+        for (int u = 0; u < G; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float rf = r[u][e];
+                int j = (int)((rf - firstf) * invf);
+                j = j < 0 ? 0 : (j > 255 ? 255 : j);
+                while (j < 255 && rf >= thr[j + 1]) ++j;
+                while (j > 0 && rf < thr[j]) --j;
+                hist_add(hist, (unsigned)j, true);
+            }
+    };
+    f32x4 ra[G], rb[G];
+    request(ra);
+    for (int g0 = 0; g0 < NG; g0 += 2 * G * NT) {      // (NG is a multiple of 2 G NT here)
+        request(rb);
+        consume(ra);
+        if (g0 + 2 * G * NT < NG) request(ra);
+        consume(rb);
+    }
+}
+
+// skimage equalize_hist tables: np.histogram(image, 256) over [min,max] (zeros included), cdf, bin centres
+__device__ __forceinline__ void histeq_run(Smem& s, const TileView& tv, int upto, double* heq_global) {
+    double mn = INFINITY, mx = -INFINITY;
+    const bool lean = upto == 0 && (tv.tw & 3) == 0 && (tv.th * (tv.tw >> 2)) % (4 * NT) == 0 && !(s.variant & 4);
+    if (lean) {
+        float rmn = INFINITY, rmx = -INFINITY;
+        minmax_plain<true>(tv, 0.0f, rmn, rmx);
+        mn = (double)rmn; mx = (double)rmx;
+    } else {
+        for_pixels<false>(s, tv, upto, nullptr, [&](float, double v, bool, bool ok) {
+            if (ok) { mn = fmin(mn, v); mx = fmax(mx, v); }
+        });
+    }
+    mn = block_min(s, mn); mx = block_max(s, mx);
+    double first = mn, last = mx;
+    if (first == last) { first -= 0.5; last += 0.5; }
+    const double step = (last - first) / 256.0;
+    auto edge = [&](int i) { return i == 256 ? last : (double)i * step + first; };       // np.linspace
+    __syncthreads();
+    clear_hists(s, false);
+    __syncthreads();
+    auto bin_of = [&](double v) {
+        int idx = (int)(((v - first) / (last - first)) * 256.0);
+        if (idx == 256) idx = 255;
+        if (idx < 0) idx = 0;
+        if (idx > 255) idx = 255;
+        if (v < edge(idx)) idx -= 1;
+        else if (v >= edge(idx + 1) && idx != 255) idx += 1;
+        return idx;
+    };
+    if (lean && mn <= mx && isfinite(mn) && isfinite(mx)) {
+        float* thr = reinterpret_cast<float*>(s.zs);                   // thr[1..255]; thr[0] unused
+        const int i = threadIdx.x;
+        if (i >= 1 && i < 256) {
+            // smallest key in [key(min), key(max)] whose bin is >= i; none: +inf (no pixel exceeds the maximum)
+            unsigned lo = fkey((float)mn), hi = fkey((float)mx);
+            float t = INFINITY;
+            if (bin_of((double)fkey_inv(hi)) >= i) {
+                while (lo < hi) {
+                    const unsigned mid = lo + ((hi - lo) >> 1);
+                    if (bin_of((double)fkey_inv(mid)) >= i) hi = mid; else lo = mid + 1;
+                }
+                t = fkey_inv(hi);
+            }
+            thr[i] = t;
+        }
+        __syncthreads();
+        const double span = last - first;
+        hist_plain(tv, thr, (float)first, (float)(256.0 / span), s.histA);
+    } else
+    for_pixels<false>(s, tv, upto, nullptr, [&](float, double v, bool, bool act) {
+        int idx = 0;
+        if (act) idx = bin_of(v);
+        hist_add(s.histA, (unsigned)idx, act);
+    });
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long c = 0ull;
+        for (int i = 0; i < 256; ++i) { c += s.histA[i]; s.zs[i] = (double)c; }
+        for (int i = 0; i < 256; ++i) {
+            s.heq[256 + i] = s.zs[i] / (double)c;
+            s.heq[i] = (edge(i) + edge(i + 1)) / 2.0;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 512; i += NT) heq_global[i] = s.heq[i];
+    __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------- statistics kernel
