@@ -1362,7 +1362,7 @@ __global__ __launch_bounds__(256) void pre_rowcheck_kernel(const PreArgs a) {
     if (threadIdx.x == 0 && bad && a.status[b] == 0) a.status[b] = 2;
 }
 
-static int pre_variant() { static const int v = getenv("CY_PRE_VARIANT") ? atoi(getenv("CY_PRE_VARIANT")) : 0; return v; }
+static int pre_variant() { const char* e = getenv("CY_PRE_VARIANT"); return e ? atoi(e) : 0; }      // (read per launch: tests/test_gpu_preproc.py switches it)
 
 hipError_t launch_preproc(const PreArgs& a0, hipStream_t s) {
     PreArgs a = a0; a.variant = pre_variant();

@@ -266,3 +266,30 @@ def test_staged_upload_reads_whole_rows_with_pread(tmp_path, monkeypatch):
     assert np.array_equal(t.cpu().numpy(), want)
     t2, ox2, oy2 = src.region(det, 100, 300, 20, 200)           # inside the resident region: reused
     assert t2 is t and (ox2, oy2) == (0, 17)
+
+
+@pytest.mark.parametrize("size", [512, 640, 132])
+def test_lean_passes_agree_with_the_general_ones(size, monkeypatch):
+    """Round 4: the statistics passes over raw whole-group tiles have lean forms (moments_plain, minmax_plain, hist_plain, the first
+    sigma-clip trip about the sample bracket's midpoint, the narrower median bracket of later clips).  CY_PRE_VARIANT switches them off
+    one bit at a time (read per launch); the preprocessed float64 image must not care: the HISTEQ channel is bit-identical (same bins,
+    same tables), the sigma-clip channels agree to 1e-12 (sums in another order, fma)."""
+    from caesar_yolo_amd import synth
+    det = detector("fp32", max_imgsz=640)
+    mos = synth.make_mosaic(2048, seed=20260105)
+    tiles = [np.ascontiguousarray(mos[y:y + size, x:x + size]) for (x, y) in [(0, 0), (700, 900), (1300, 200)]]
+    mosaic, xy = _mosaic(det, tiles)
+    cfg = PP.DataPreprocessor(PIPES["chan3_minmax"](PP)).program()
+    monkeypatch.setenv("CY_PRE_VARIANT", "0")
+    base, st0 = det.preproc_planes(mosaic, xy, size, size, cfg)
+    base = base.cpu().numpy()
+    par0 = det.preproc_params(len(xy)).copy()
+    assert st0.cpu().tolist() == [0, 0, 0]
+    for variant in (2, 4, 8, 64, 2 | 4 | 8 | 64):
+        monkeypatch.setenv("CY_PRE_VARIANT", str(variant))
+        got, st = det.preproc_planes(mosaic, xy, size, size, cfg)
+        got = got.cpu().numpy()
+        assert st.cpu().tolist() == [0, 0, 0]
+        np.testing.assert_array_equal(got[:, 2], base[:, 2], err_msg="HISTEQ channel, variant %d" % variant)
+        np.testing.assert_allclose(got[:, :2], base[:, :2], rtol=1e-12, atol=1e-12, err_msg="sigma-clip channels, variant %d" % variant)
+        np.testing.assert_allclose(det.preproc_params(len(xy)), par0, rtol=1e-12, atol=0, err_msg="solved parameters, variant %d" % variant)
