@@ -2498,6 +2498,11 @@ __global__ __launch_bounds__(512, (NB * MI <= 4 && RING == 2) ? 2 : 1) void conv
     // ds_bpermute_b32 per load, or ~20 DPP / permlane-swap moves).  Built with ds_bpermute (the next chunk's registers transposed behind
     // the current chunk's MFMAs; bit-identical, 234 conv / forward tests green): every layer 2-14 % SLOWER (forward 28.34 vs 27.80 ms):
     // the 16 permutes per wave and chunk cost two to three times what the better access pattern gives.  Not kept.
+    // Round 4: the eight requests of a chunk (four weight pieces, four pixel loads per wave) issued one behind each of the chunk's eight
+    // MFMA groups instead of together at its start, where all eight waves stand behind the barrier (same order, same counted waits;
+    // bit-identical, 296 conv / forward tests green): forward 27.31-27.48 vs 27.37-27.38 ms, the K-heavy layers 0-2 % SLOWER.  Not kept.
+    // Also round 4: a persistent-kernel grid of ncu - 8 / 16 / 32 workgroups (CUs left to the side streams) changes nothing in the
+    // config-5 pass (4864-4893 vs 4890-4905 tiles/s).
     const bool no_dma = CY_STAMPS_ENABLED && (a.dbg & 1), no_rd = CY_STAMPS_ENABLED && (a.dbg & 2), no_mma = CY_STAMPS_ENABLED && (a.dbg & 4),
                no_px = CY_STAMPS_ENABLED && (a.dbg & 8);
     const bool reqw = wave < NDW;
