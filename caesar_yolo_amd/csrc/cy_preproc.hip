@@ -336,11 +336,12 @@ __device__ __forceinline__ bool in_set(const ClipSet& cs, float r, double v, boo
 // plain LDS atomics serialise on that address (measured: 13 ms per 96-tile batch of the 3-channel 640^2 pipeline).  Up to
 // three rounds of "count the lanes that share the first pending lane's bin, one atomic for all of them" take care of the
 // concentrated case; whatever is still pending afterwards (uniformly spread low bits) goes through ordinary atomics.
+template <int ROUNDS = 3>
 __device__ __forceinline__ void hist_add(unsigned* hist, unsigned bin, bool active) {
     const int lane = threadIdx.x & 63;
     unsigned long long todo = __ballot(active);
 #pragma unroll 1
-    for (int it = 0; it < 3 && todo != 0ull; ++it) {
+    for (int it = 0; it < ROUNDS && todo != 0ull; ++it) {
         const int leader = __ffsll((long long)todo) - 1;
         const unsigned lb = (unsigned)__shfl((int)bin, leader);
         const unsigned long long same = __ballot(active && bin == lb);
@@ -673,8 +674,15 @@ __device__ __forceinline__ void select_cand(Smem& s, unsigned nc, unsigned long 
             const bool act = i < nc;
             const unsigned key = act ? s.cand[i] : 0u;
             const unsigned bin = (key >> shift) & nbm;
-            hist_add(s.histA, bin, act && (key & pmask) == pA);
-            if (two) hist_add(s.histB, bin, act && (key & pmask) == pB);
+            // the leading level sees one or two bins (a bracket's keys share sign and exponent): one aggregation round; below it the
+            // bins are the keys' middle and low bits, evenly spread: plain atomics (three rounds everywhere: clip stage +9 %, round 4)
+            if (lvl == 0) {
+                hist_add<1>(s.histA, bin, act && (key & pmask) == pA);
+                if (two) hist_add<1>(s.histB, bin, act && (key & pmask) == pB);
+            } else {
+                hist_add<0>(s.histA, bin, act && (key & pmask) == pA);
+                if (two) hist_add<0>(s.histB, bin, act && (key & pmask) == pB);
+            }
         }
         __syncthreads();
         unsigned binA, binB; unsigned long long befA, befB;
@@ -987,6 +995,7 @@ __device__ __forceinline__ void minmax_plain(const TileView& tv, float tf, float
 // edges keeps it so), hence bin(r) = number of i in 1..255 with r >= thr[i], thr[i] = the smallest float whose bin is >= i (found once
 // per tile by bisection over the float keys with the exact float64 formula).  Per pixel: a float32 guess, a walk along thr (zero or one
 // step) and the aggregated increment -- instead of a float64 division, two edge evaluations and their compares.
+template <int ROUNDS>
 __device__ __forceinline__ void hist_plain(const TileView& tv, const float* thr, float firstf, float invf, unsigned* hist) {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const int GR = tv.tw >> 2, NG = tv.th * GR;
@@ -1016,7 +1025,7 @@ __device__ __forceinline__ void hist_plain(const TileView& tv, const float* thr,
                 j = j < 0 ? 0 : (j > 255 ? 255 : j);
                 while (j < 255 && rf >= thr[j + 1]) ++j;
                 while (j > 0 && rf < thr[j]) --j;
-                hist_add(hist, (unsigned)j, true);
+                hist_add<ROUNDS>(hist, (unsigned)j, true);
             }
     };
     f32x4 ra[G], rb[G];
@@ -1077,7 +1086,9 @@ __device__ __forceinline__ void histeq_run(Smem& s, const TileView& tv, int upto
         }
         __syncthreads();
         const double span = last - first;
-        hist_plain(tv, thr, (float)first, (float)(256.0 / span), s.histA);
+        // one aggregation round: the background's bin; what is left goes through ordinary atomics (three rounds: +5 % on the chan3
+        // pipeline, none: the same as one)
+        hist_plain<1>(tv, thr, (float)first, (float)(256.0 / span), s.histA);
     } else
     for_pixels<false>(s, tv, upto, nullptr, [&](float, double v, bool, bool act) {
         int idx = 0;
