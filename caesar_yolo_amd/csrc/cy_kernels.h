@@ -202,6 +202,7 @@ struct PreArgs {
     int new_h, new_w;                      // resized size (== th,tw when no resize)
     int* counters;                         // context counters or null: [2] += median-bracket hits, [3] += misses (cy_preproc.hip)
     int variant;                           // developer A/B switch of the statistics kernel (CY_PRE_VARIANT; 0 = shipped form)
+    int fuse01;                            // set by the launch: programs 0 and 1 run in one workgroup (shared initial set)
 };
 hipError_t launch_preproc(const PreArgs& a, hipStream_t s);
 hipError_t launch_preproc_planes(const PreArgs& a, hipStream_t s);    // statistics + checks + float64 planes into a.scratch (no packing)

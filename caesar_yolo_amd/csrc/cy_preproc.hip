@@ -701,8 +701,13 @@ __device__ __forceinline__ void select_cand(Smem& s, unsigned nc, unsigned long 
 // previous median also collects the raw keys inside a narrow bracket around that median (clipping moves the median by a
 // tiny fraction of sigma), and the new median is selected among them in LDS.  A bracket that misses the median or overflows
 // falls back to the three-pass radix select; the bracket width follows the density measured by the previous pass.
+// What a run on the raw pixels learns about its INITIAL set (every non-zero finite pixel outside the box) before the first clip: shared by
+// the sigma-clip stages that open two channel programs of one tile (round 4; chan3: both sigma-clip channels start from the same set)
+struct InitCache { bool valid; int use_box; double fract; unsigned long long n; double mean, sd, med, density; };
+
 template <bool RAW>
-__device__ __forceinline__ ClipStats sigma_clip_run(Smem& s, const TileView& tv, int upto, double slo, double sup, int use_box, double mask_fract) {
+__device__ __forceinline__ ClipStats sigma_clip_run(Smem& s, const TileView& tv, int upto, double slo, double sup, int use_box, double mask_fract,
+                                                    InitCache* ic = nullptr) {
     ClipSet cs{-INFINITY, INFINITY, use_box, 0, 0, 0, 0, -INFINITY, INFINITY};
     if (use_box) {
         const int xc = tv.tw / 2, yc = tv.th / 2;
@@ -731,7 +736,8 @@ __device__ __forceinline__ ClipStats sigma_clip_run(Smem& s, const TileView& tv,
     // 640^2 tile, read as whole rows) go to s.cand, their 0.48 / 0.52 quantiles (radix select in LDS) bound the true median with
     // ~5 sigma of the sampling error of a rank, and the first pass collects the set members between them like every later pass.
     // A bracket that misses (or overflows) falls back to the histogram passes, so the median stays exact.
-    if (RAW) {
+    const bool resume = RAW && ic && ic->valid && ic->use_box == use_box && ic->fract == mask_fract;
+    if (RAW && !resume) {
         const int rstep = tv.th >= 52 ? tv.th / 26 : 1;
         __syncthreads();
         if (threadIdx.x == 0) s.ncand = 0u;
@@ -778,8 +784,16 @@ __device__ __forceinline__ ClipStats sigma_clip_run(Smem& s, const TileView& tv,
     // of the trips, and the listing cost more than the saved passes (clip stage 1.31 -> 1.48 ms per 225 tiles).
     const bool sampled = RAW && br.on && !(s.variant & 8);
     if (sampled) { K = 0.5 * (br.vl + br.vh); if (!isfinite(K)) K = 0.0; }
+    bool skip_trip = resume;                   // the first trip's results come from the cache
 #pragma unroll 1
     for (;;) {
+      bool hit = false;
+      if (skip_trip) {
+        skip_trip = false;
+        n = ic->n; mean = ic->mean; sd = ic->sd; med = ic->med; density = ic->density;
+        if (n == 0) { mean = sd = med = NAN; break; }
+        c = 0;
+      } else {
         const bool radix_trip = !br.on || !br.collect;   // this trip's median (if needed) comes from the radix select
         unsigned long long ts = pre_now();
         set_moments<RAW>(s, tv, upto, cs, K, radix_trip && c != -1, br, &n, &mean, &sd, &below, &ncand);
@@ -787,7 +801,6 @@ __device__ __forceinline__ ClipStats sigma_clip_run(Smem& s, const TileView& tv,
         if (c >= 1 && n == nprev) break;      // the clip removed nothing: converged, (mean, sd, med) describe this very set
         if (n == 0) { mean = sd = med = NAN; break; }
         if (br.on && ncand > 0) density = (double)ncand / (br.vh - br.vl);          // measured (also when the bracket overflowed or missed)
-        bool hit = false;
         if (c != -1) {
             const unsigned long long kA = (n - 1) / 2, kB = n / 2;
             hit = br.on && br.collect && ncand <= (unsigned)NCAND && below <= kA && kB < below + ncand;
@@ -815,9 +828,11 @@ __device__ __forceinline__ ClipStats sigma_clip_run(Smem& s, const TileView& tv,
                 pre_acc(1, ts);
             }
         }
+      }
         if (c == -2) {
             if (sampled && hit && density > 0.0) {
                 c = 0;                        // moments about the sample bracket's midpoint, density from its population
+                if (ic) { ic->valid = true; ic->use_box = use_box; ic->fract = mask_fract; ic->n = n; ic->mean = mean; ic->sd = sd; ic->med = med; ic->density = density; }
             } else {
                 // second trip over the initial set: accurate moments about its median, and the density of members around the median
                 // (count inside +-sd/32; sd of the first trip is good enough for that) to size the first bracket
@@ -1115,15 +1130,32 @@ __device__ __forceinline__ void histeq_run(Smem& s, const TileView& tv, int upto
 // scratch memory (ScratchSize 3352 B per lane, ~570 MB of scratch writes per launch) and read every stage from there per pixel.
 __global__ __launch_bounds__(NT) void pre_stats_kernel(const PreArgs a) {
     __shared__ Smem s;
-    const int b = blockIdx.x % a.B, p = blockIdx.x / a.B;      // program-major: the long sigma-clip programs first, the short HISTEQ one last
+    // job-major: the long sigma-clip jobs first, the short HISTEQ one last.  A job is one channel program -- or, when the host found
+    // that programs 0 and 1 both open with a sigma-clip stage on the same initial set (a.fuse01; chan3), those two one after the other
+    // in ONE workgroup: the second run takes the row sample, the first pass and the initial median from the first (InitCache), and the
+    // batch's long jobs fit the CUs in one round instead of two.
+    const int b = blockIdx.x % a.B, job = blockIdx.x / a.B;
+    const int pfirst = a.fuse01 ? (job == 0 ? 0 : job + 1) : job, pcount = a.fuse01 && job == 0 ? 2 : 1;
     // dynamically indexed members (prog[p].st[k], txy[2b]) are read straight from the kernel-argument segment
     typedef const __attribute__((address_space(4))) char* kptr;
     const kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
-    const kptr kprog = ka + offsetof(PreArgs, prog) + (size_t)p * sizeof(PreProgram);
     auto kint = [](kptr q) { return *(const __attribute__((address_space(4))) int*)q; };
     auto kdbl = [](kptr q) { return *(const __attribute__((address_space(4))) double*)q; };
-    const int nst = kint(kprog + offsetof(PreProgram, n));
     if (threadIdx.x == 0) s.variant = a.variant;
+    const int tx0 = kint(ka + offsetof(PreArgs, txy) + (size_t)(2 * b) * 4), ty0 = kint(ka + offsetof(PreArgs, txy) + (size_t)(2 * b + 1) * 4);
+    const float* tbase = a.mosaic + (size_t)ty0 * a.MW + tx0;
+    // bytes addressable from the tile origin: up to the end of the mosaic (a 16-byte load of the last group of a row may
+    // reach into the next row or, on the mosaic's last row, past the end: there the range check returns zeros)
+    const size_t tbytes = ((size_t)(a.MH - ty0) * a.MW - tx0) * 4;
+    TileView tv{tbase, a.MW, a.tw, a.th, a.tw * a.th,
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tbase), 0, (unsigned)(tbytes > 0xFFFFFF00ull ? 0xFFFFFF00ull : tbytes), 0x00020000)};
+    InitCache ic{false, 0, 0.0, 0ull, 0.0, 0.0, 0.0, 0.0};
+    int status = 0, hits = 0, misses = 0;
+  for (int pi = 0; pi < pcount; ++pi) {
+    const int p = pfirst + pi;
+    const kptr kprog = ka + offsetof(PreArgs, prog) + (size_t)p * sizeof(PreProgram);
+    const int nst = kint(kprog + offsetof(PreProgram, n));
+    __syncthreads();
     if (threadIdx.x < MAX_STAGES) {
         const int k = threadIdx.x;
         const kptr ks = kprog + offsetof(PreProgram, st) + (size_t)k * sizeof(PreStage);
@@ -1131,17 +1163,9 @@ __global__ __launch_bounds__(NT) void pre_stats_kernel(const PreArgs a) {
         s.q0[k] = kdbl(ks + offsetof(PreStage, p0)); s.q1[k] = kdbl(ks + offsetof(PreStage, p1));
         s.flag[k] = kint(ks + offsetof(PreStage, flag));
     }
-    const int tx0 = kint(ka + offsetof(PreArgs, txy) + (size_t)(2 * b) * 4), ty0 = kint(ka + offsetof(PreArgs, txy) + (size_t)(2 * b + 1) * 4);
     double* params = a.params + ((size_t)b * 3 + p) * PSTRIDE;
     double* heq = a.histeq + ((size_t)b * 3 + p) * HEQ_STRIDE;
-    const float* tbase = a.mosaic + (size_t)ty0 * a.MW + tx0;
-    // bytes addressable from the tile origin: up to the end of the mosaic (a 16-byte load of the last group of a row may
-    // reach into the next row or, on the mosaic's last row, past the end: there the range check returns zeros)
-    const size_t tbytes = ((size_t)(a.MH - ty0) * a.MW - tx0) * 4;
-    TileView tv{tbase, a.MW, a.tw, a.th, a.tw * a.th,
-                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tbase), 0, (unsigned)(tbytes > 0xFFFFFF00ull ? 0xFFFFFF00ull : tbytes), 0x00020000)};
     __syncthreads();
-    int status = 0, hits = 0, misses = 0;
     for (int k = 0; k < nst; ++k) {
         const int op = s.op[k];
         const double p0 = s.q0[k], p1 = s.q1[k];
@@ -1153,7 +1177,7 @@ __global__ __launch_bounds__(NT) void pre_stats_kernel(const PreArgs a) {
             const double slo = op == OP_CLIP ? (p0 != 0.0 ? p0 : 3.0) : p0, sup = op == OP_CLIP ? (p1 != 0.0 ? p1 : 3.0) : p0;
             const int ubox = op == OP_BKG ? flag : 0;
             const double fract = op == OP_BKG ? p1 : 0.0;
-            const ClipStats r = k == 0 ? sigma_clip_run<true>(s, tv, k, slo, sup, ubox, fract) : sigma_clip_run<false>(s, tv, k, slo, sup, ubox, fract);
+            const ClipStats r = k == 0 ? sigma_clip_run<true>(s, tv, k, slo, sup, ubox, fract, pcount > 1 ? &ic : nullptr) : sigma_clip_run<false>(s, tv, k, slo, sup, ubox, fract);
             hits += r.hits; misses += r.misses;
             if (op == OP_BKG) { o0 = r.mean; if (r.n == 0) status = 1; }
             else if (op == OP_SHIFT) { o0 = r.mean + p0 * r.std; o1 = r.mean; o2 = r.std; if (r.n == 0) status = 1; }
@@ -1206,6 +1230,7 @@ __global__ __launch_bounds__(NT) void pre_stats_kernel(const PreArgs a) {
         }
         __syncthreads();
     }
+  }
     if (threadIdx.x == 0 && status) atomicMax(a.status + b, status);
     if (threadIdx.x == 0 && a.counters && (hits | misses)) { atomicAdd(a.counters + 2, hits); atomicAdd(a.counters + 3, misses); }
 }
@@ -1373,13 +1398,24 @@ __global__ __launch_bounds__(256) void pre_rowcheck_kernel(const PreArgs a) {
     if (threadIdx.x == 0 && bad && a.status[b] == 0) a.status[b] = 2;
 }
 
+static int pre_variant_env() { const char* e = getenv("CY_PRE_VARIANT"); return e ? atoi(e) : 0; }
+// programs 0 and 1 open with a sigma-clip stage over the same initial set (same box): one workgroup runs both (pre_stats_kernel)
+static int pre_fuse01(const PreArgs& a) {
+    if (a.nprog != 3 || a.prog[0].n < 1 || a.prog[1].n < 1 || (pre_variant_env() & 4096)) return 0;
+    const PreStage &x = a.prog[0].st[0], &y = a.prog[1].st[0];
+    auto clip_kind = [](int op) { return op == OP_BKG || op == OP_SHIFT || op == OP_CLIP; };
+    if (!clip_kind(x.op) || !clip_kind(y.op)) return 0;
+    const int bx = x.op == OP_BKG ? x.flag : 0, by = y.op == OP_BKG ? y.flag : 0;
+    const double fx = x.op == OP_BKG ? x.p1 : 0.0, fy = y.op == OP_BKG ? y.p1 : 0.0;
+    return bx == by && fx == fy;
+}
 static int pre_variant() { const char* e = getenv("CY_PRE_VARIANT"); return e ? atoi(e) : 0; }      // (read per launch: tests/test_gpu_preproc.py switches it)
 
 hipError_t launch_preproc(const PreArgs& a0, hipStream_t s) {
-    PreArgs a = a0; a.variant = pre_variant();
+    PreArgs a = a0; a.variant = pre_variant(); a.fuse01 = pre_fuse01(a);
     hipError_t e = hipMemsetAsync(a.status, 0, a.B * sizeof(int), s);
     if (e != hipSuccess) return e;
-    if (a.nprog > 0) hipLaunchKernelGGL(pre_stats_kernel, dim3(a.B * a.nprog), dim3(NT), 0, s, a);
+    if (a.nprog > 0) hipLaunchKernelGGL(pre_stats_kernel, dim3(a.B * (a.nprog - a.fuse01)), dim3(NT), 0, s, a);
     hipLaunchKernelGGL(pre_rowcheck_kernel, dim3(a.B), dim3(256), 0, s, a);
     const int npx = a.H * a.W;
     int gx = (npx + 255) / 256; if (gx > 1024) gx = 1024;
@@ -1399,10 +1435,10 @@ hipError_t launch_preproc(const PreArgs& a0, hipStream_t s) {
 // statistics + rejection checks + the preprocessed image itself as float64 planes [B][3][th*tw] in a.scratch (what
 // DataPreprocessor returns to Analyzer.predict, caesar_yolo/evaluation.py:157-161): parity witness and the plotting input
 hipError_t launch_preproc_planes(const PreArgs& a0, hipStream_t s) {
-    PreArgs a = a0; a.variant = pre_variant();
+    PreArgs a = a0; a.variant = pre_variant(); a.fuse01 = pre_fuse01(a);
     hipError_t e = hipMemsetAsync(a.status, 0, a.B * sizeof(int), s);
     if (e != hipSuccess) return e;
-    if (a.nprog > 0) hipLaunchKernelGGL(pre_stats_kernel, dim3(a.B * a.nprog), dim3(NT), 0, s, a);
+    if (a.nprog > 0) hipLaunchKernelGGL(pre_stats_kernel, dim3(a.B * (a.nprog - a.fuse01)), dim3(NT), 0, s, a);
     hipLaunchKernelGGL(pre_rowcheck_kernel, dim3(a.B), dim3(256), 0, s, a);
     int gs = (a.th * a.tw + 255) / 256; if (gs > 1024) gs = 1024;
     hipLaunchKernelGGL(pre_plane_kernel, dim3(gs, a.B), dim3(256), 0, s, a);
