@@ -1401,7 +1401,10 @@ __global__ __launch_bounds__(256) void pre_rowcheck_kernel(const PreArgs a) {
 static int pre_variant_env() { const char* e = getenv("CY_PRE_VARIANT"); return e ? atoi(e) : 0; }
 // programs 0 and 1 open with a sigma-clip stage over the same initial set (same box): one workgroup runs both (pre_stats_kernel)
 static int pre_fuse01(const PreArgs& a) {
-    if (a.nprog != 3 || a.prog[0].n < 1 || a.prog[1].n < 1 || (pre_variant_env() & 4096)) return 0;
+    // Opt-in (CY_PRE_VARIANT bit 4096): alone the chan3 statistics take 2.75 instead of 2.91 ms per 225 tiles of 640^2, but inside the
+    // pipelined pass of config 5 the rate is the same or a hair lower (4991 / 4991 vs 4993 / 5027 tiles/s on one box): the saved CU time is
+    // paid back by workgroups that hold their CU twice as long.  Bit-identical statistics either way (tests/test_gpu_preproc.py).
+    if (a.nprog != 3 || a.prog[0].n < 1 || a.prog[1].n < 1 || !(pre_variant_env() & 4096)) return 0;
     const PreStage &x = a.prog[0].st[0], &y = a.prog[1].st[0];
     auto clip_kind = [](int op) { return op == OP_BKG || op == OP_SHIFT || op == OP_CLIP; };
     if (!clip_kind(x.op) || !clip_kind(y.op)) return 0;

@@ -271,8 +271,8 @@ def test_staged_upload_reads_whole_rows_with_pread(tmp_path, monkeypatch):
 @pytest.mark.parametrize("size", [512, 640, 132])
 def test_lean_passes_agree_with_the_general_ones(size, monkeypatch):
     """Round 4: the statistics passes over raw whole-group tiles have lean forms (moments_plain, minmax_plain, hist_plain, the first
-    sigma-clip trip about the sample bracket's midpoint, the narrower median bracket of later clips, the two sigma-clip programs of chan3 in one workgroup with a shared initial set = bit 4096).
-    CY_PRE_VARIANT switches them off
+    sigma-clip trip about the sample bracket's midpoint, the narrower median bracket of later clips, and, opt-in, the two sigma-clip programs of chan3 in one workgroup with a shared initial set = bit 4096).
+    CY_PRE_VARIANT switches them off (on)
     one bit at a time (read per launch); the preprocessed float64 image must not care: the HISTEQ channel is bit-identical (same bins,
     same tables), the sigma-clip channels agree to 1e-12 (sums in another order, fma)."""
     from caesar_yolo_amd import synth
