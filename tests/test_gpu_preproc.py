@@ -268,6 +268,29 @@ def test_staged_upload_reads_whole_rows_with_pread(tmp_path, monkeypatch):
     assert t2 is t and (ox2, oy2) == (0, 17)
 
 
+@pytest.mark.parametrize("pname", ["zscale_minmax", "minmax", "clip_1_3", "bkg_box", "full"])
+def test_lean_passes_agree_with_the_general_ones_other_pipelines(pname, monkeypatch):
+    """The same switch on the other pipelines: MINMAX behind nothing / behind [ZSCALE] (raw_threshold), a sigma clip whose lower bound
+    sits inside the noise (1 sigma), a masked box (general loop either way) and the five-stage chain (raw first stage only)."""
+    from caesar_yolo_amd import synth
+    det = detector("fp32", max_imgsz=640)
+    mos = synth.make_mosaic(2048, seed=20260104)
+    size = 512
+    tiles = [np.ascontiguousarray(mos[y:y + size, x:x + size]) for (x, y) in [(0, 0), (900, 700)]]
+    mosaic, xy = _mosaic(det, tiles)
+    cfg = PP.DataPreprocessor(PIPES[pname](PP)).program()
+    monkeypatch.setenv("CY_PRE_VARIANT", "0")
+    base, st0 = det.preproc_planes(mosaic, xy, size, size, cfg)
+    base, st0 = base.cpu().numpy(), st0.cpu().tolist()
+    par0 = det.preproc_params(len(xy)).copy()
+    for variant in (2, 4, 8, 64, 2 | 4 | 8 | 64):
+        monkeypatch.setenv("CY_PRE_VARIANT", str(variant))
+        got, st = det.preproc_planes(mosaic, xy, size, size, cfg)
+        assert st.cpu().tolist() == st0
+        np.testing.assert_allclose(got.cpu().numpy(), base, rtol=1e-12, atol=1e-12, err_msg="%s, variant %d" % (pname, variant))
+        np.testing.assert_allclose(det.preproc_params(len(xy)), par0, rtol=1e-12, atol=0, err_msg="%s parameters, variant %d" % (pname, variant))
+
+
 @pytest.mark.parametrize("size", [512, 640, 132])
 def test_lean_passes_agree_with_the_general_ones(size, monkeypatch):
     """Round 4: the statistics passes over raw whole-group tiles have lean forms (moments_plain, minmax_plain, hist_plain, the first
