@@ -53,18 +53,28 @@ def shard(items, rank, world):
 # n*w plus a fixed launch/pipeline overhead per batch (measured on MI355X at world 8: 198 full tiles in one batch 28.7 ms,
 # in two 30.5 ms, in three 36.6 ms; full rate 7285 tiles/s -> 12-25 tile-equivalents per batch; small batches of
 # ragged tiles run well below the full rate).
-BATCH_OVERHEAD_TILES = 26.0      # refit after the fused stem kernel: world 8 and 4 emulation (tools/emulate_ranks.py), 0.116 ms per tile
-SMALL_BATCH_EXTRA_TILES = 7.5    # (refit in round 3 on the N = 8 emulation: the rank that inherits the four small batches ran 1.0 ms behind the others at 5.0)
+# Round 4 refit on the emulation of N = 2 / 4 / 8 (tools/emulate_ranks.py; 0.1008 ms per tile-equivalent): a rank's FIRST batch pays its
+# preprocessing and the pipeline fill in full, later batches run behind the previous one's forward pass, and a small batch (ragged edge
+# tiles, or a few full tiles) runs its deep layers far below the full rate wherever it runs (the small-batch lane shares the GPU with
+# the main one).  Residuals of the fit: -3 .. +3 % of a rank's time over the seven measured ranks.
+BATCH_OVERHEAD_FIRST = 23.0
+BATCH_OVERHEAD_NEXT = 11.5
+SMALL_BATCH_EXTRA_TILES = 21.0
+BATCH_OVERHEAD_TILES = BATCH_OVERHEAD_FIRST      # (name kept for tools that print the model)
 
 
 def _rank_cost(segments, cost, batch):
     """segments: list of (shape, n tiles).  Estimated pass time in tile-equivalents."""
-    t = 0.0
+    t, nb = 0.0, 0
     for shp, n in segments:
         if n:
-            t += n * cost[shp] + BATCH_OVERHEAD_TILES * ((n + batch - 1) // batch)
-            if n < 64:
-                t += SMALL_BATCH_EXTRA_TILES           # the deep layers do not fill the chip: below the linear model
+            k = (n + batch - 1) // batch
+            t += n * cost[shp]
+            nb += k
+            if n < 64:                                 # the deep layers do not fill the chip: below the linear model
+                t += SMALL_BATCH_EXTRA_TILES
+    if nb:
+        t += BATCH_OVERHEAD_FIRST + BATCH_OVERHEAD_NEXT * (nb - 1)
     return t
 
 
