@@ -59,20 +59,21 @@ def shard(items, rank, world):
 # the main one).  Residuals of the fit: -3 .. +3 % of a rank's time over the seven measured ranks.
 BATCH_OVERHEAD_FIRST = 23.0
 BATCH_OVERHEAD_NEXT = 11.5
-SMALL_BATCH_EXTRA_TILES = 21.0
+SMALL_BATCH_EXTRA_TILES = 20.0   # minus 1.0 per full-size batch of the same rank to run beside (up to three)
 BATCH_OVERHEAD_TILES = BATCH_OVERHEAD_FIRST      # (name kept for tools that print the model)
 
 
 def _rank_cost(segments, cost, batch):
     """segments: list of (shape, n tiles).  Estimated pass time in tile-equivalents."""
     t, nb = 0.0, 0
+    nbig = sum((n + batch - 1) // batch for _, n in segments if n >= 128)
     for shp, n in segments:
         if n:
             k = (n + batch - 1) // batch
             t += n * cost[shp]
             nb += k
             if n < 64:                                 # the deep layers do not fill the chip: below the linear model
-                t += SMALL_BATCH_EXTRA_TILES
+                t += SMALL_BATCH_EXTRA_TILES - 1.0 * min(nbig, 3)
     if nb:
         t += BATCH_OVERHEAD_FIRST + BATCH_OVERHEAD_NEXT * (nb - 1)
     return t
