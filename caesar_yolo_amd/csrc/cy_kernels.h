@@ -112,7 +112,8 @@ int conv_variant(Precision p, const ConvArgs& a);          // which kernel launc
 const char* conv_variant_name(int v);
 void debug_read_stamps(unsigned long long* out8, bool reset);
 void debug_read_wg_stamps(unsigned long long* out, int n);      // raw per-workgroup phase records (n x 4), stamped builds   // developer diagnostics (CY_DBG=64)
-void debug_read_pre_stamps(unsigned long long* out8, bool reset);   // phases of pre_stats_kernel (cy_preproc.hip), stamped builds only
+void debug_read_pre_stamps(unsigned long long* out8, bool reset);
+void debug_fastdiv(const double* d_a, const double* d_b, double* d_fast, double* d_ref, int n);      // fast_div vs `/` (cy_preproc.hip)   // phases of pre_stats_kernel (cy_preproc.hip), stamped builds only
 hipError_t launch_stem(Precision p, const StemArgs& a, hipStream_t s);
 hipError_t launch_stem_down(const StemDownArgs& a, hipStream_t s);
 long stem_down_blocks(const StemDownArgs& a);

@@ -1256,12 +1256,92 @@ __device__ __forceinline__ void tile_channels(const PreArgs& a, int b, double ra
 // through the argument block and the parameter arrays (loads the compiler cannot hoist over the output stores) and finding the
 // HISTEQ knot by bisection in global memory made the chan3 pipeline's pack 1.32 ms per 225 tiles of 640^2 against 0.34 ms for a
 // plain copy: ~470 instructions per pixel.
+// Quotients by a per-tile constant.  A float64 division compiles to (ISA of `a / b` on gfx950)
+//   d = div_scale(b), n = div_scale(a), r = rcp(d), two Newton steps r <- fma(r, fma(-d, r, 1), r), q0 = n * r, e = fma(-d, q0, n),
+//   q = div_fmas(e, r, q0), div_fixup(q, b, a):
+// eleven instructions, of which everything up to r depends on b only.  div_scale is the identity -- and div_fmas a plain fma, div_fixup the
+// identity -- unless an operand is zero / denormal / non-finite or the exponents are extreme (ISA manual, V_DIV_SCALE_F64); in that
+// regime the quotient is  fma(fma(-b, a * r, a), r, a * r)  with r from the same rcp + two steps: the SAME instruction sequence on the same
+// values, hence the same bits as `a / b`.  fast_div takes that path for |b| in [2^-500, 2^500] and a == 0 or |a| in [2^-400, 2^400], and
+// divides otherwise.  tests/test_gpu_preproc.py::test_fast_division_is_the_division compares 2^22 pairs bit for bit (cy_debug_fastdiv).
+struct FastDiv { double b, nb, r; int ok; };
+__device__ __forceinline__ unsigned hi_abs(double x) { return (unsigned)((unsigned long long)__double_as_longlong(x) >> 32) & 0x7FFFFFFFu; }
+__device__ __forceinline__ FastDiv fast_div_setup(double b) {
+    FastDiv f; f.b = b; f.nb = -b;
+    const unsigned e = hi_abs(b) >> 20;                             // biased exponent
+    f.ok = e >= 1023u - 500u && e <= 1023u + 500u;
+    double r = __builtin_amdgcn_rcp(b);
+    r = __builtin_fma(r, __builtin_fma(-b, r, 1.0), r);
+    r = __builtin_fma(r, __builtin_fma(-b, r, 1.0), r);
+    f.r = r;
+    return f;
+}
+__device__ __forceinline__ double fast_div(double a, double b, double nb, double r, int ok) {
+    const unsigned e = hi_abs(a) >> 20;
+    const bool safe = ok && ((e >= 1023u - 400u && e <= 1023u + 400u) || a == 0.0);
+    if (__builtin_expect(!safe, 0)) return a / b;
+    const double q0 = a * r;
+    return __builtin_fma(__builtin_fma(nb, q0, a), r, q0);
+}
+__global__ void fastdiv_probe_kernel(const double* a, const double* b, double* fast, double* ref, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const FastDiv f = fast_div_setup(b[i]);
+    fast[i] = fast_div(a[i], f.b, f.nb, f.r, f.ok);
+    ref[i] = a[i] / b[i];
+}
+void debug_fastdiv(const double* d_a, const double* d_b, double* d_fast, double* d_ref, int n) {
+    hipLaunchKernelGGL(fastdiv_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, d_a, d_b, d_fast, d_ref, n);
+    hipDeviceSynchronize();
+}
+
 struct PackChain {
     int n[3]; int op[3][MAX_STAGES];
     double q0[3][MAX_STAGES], q1[3][MAX_STAGES], par[3][MAX_STAGES * 4];
+    double db[3][MAX_STAGES], dr[3][MAX_STAGES]; int dok[3][MAX_STAGES];      // FastDiv of the stage's divisor (ZSCALE: vmax - vmin, MINMAX: max - min)
     float hinv[3];
     double heq[3][512];
+    double hslope[3][256];                                                     // HISTEQ: slope between knots j and j + 1 (divided once per tile)
 };
+// apply_stage with the divisions of the per-tile constants taken from PackChain: same values, bit for bit
+__device__ __forceinline__ double apply_stage_pack(const PackChain& pc, int p, int k, double v) {
+    const int op = pc.op[p][k];
+    const double* sp = pc.par[p] + k * 4;
+    const bool c = cond_of(v);
+    double o = v;
+    switch (op) {
+        case OP_BKG: o = v - sp[0]; break;
+        case OP_SHIFT: o = v - sp[0]; if (o < 0.0) o = 0.0; break;
+        case OP_CLIP: if (o < sp[0]) o = sp[0]; if (o > sp[1]) o = sp[1]; break;
+        case OP_ZSCALE: {
+            o = v - sp[0];
+            const double rng = pc.db[p][k];
+            if (rng != 0.0) o = fast_div(o, rng, -rng, pc.dr[p][k], pc.dok[p][k]);
+            o = fmin(fmax(o, 0.0), 1.0);
+            break;
+        }
+        case OP_HISTEQ: {
+            const double* xp = pc.heq[p]; const double* fp = pc.heq[p] + 256;
+            if (v > xp[255]) { o = fp[255]; break; }
+            if (v < xp[0]) { o = fp[0]; break; }
+            int j = (int)((float)(v - xp[0]) * pc.hinv[p]);
+            j = j < 0 ? 0 : (j > 255 ? 255 : j);
+            while (j < 255 && xp[j + 1] <= v) ++j;
+            while (j > 0 && xp[j] > v) --j;
+            if (j == 255) { o = fp[255]; break; }
+            if (xp[j] == v) { o = fp[j]; break; }
+            o = pc.hslope[p][j] * (v - xp[j]) + fp[j];
+            break;
+        }
+        case OP_MINMAX: {
+            const double d = pc.db[p][k];
+            o = fast_div(v - sp[0], d, -d, pc.dr[p][k], pc.dok[p][k]) * (pc.q1[p][k] - pc.q0[p][k]) + pc.q0[p][k];
+            break;
+        }
+        default: break;
+    }
+    return c ? o : 0.0;
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void pre_pack_kernel(const PreArgs a) {
@@ -1283,6 +1363,8 @@ __global__ __launch_bounds__(256) void pre_pack_kernel(const PreArgs a) {
         pc.q0[p][k] = kdbl(ks + offsetof(PreStage, p0)); pc.q1[p][k] = kdbl(ks + offsetof(PreStage, p1));
         const double* sp = a.params + ((size_t)b * 3 + p) * PSTRIDE + k * 4;
         for (int j = 0; j < 4; ++j) pc.par[p][k * 4 + j] = sp[j];
+        const FastDiv fd = fast_div_setup(sp[1] - sp[0]);               // (both stages with a division divide by sp[1] - sp[0])
+        pc.db[p][k] = fd.b; pc.dr[p][k] = fd.r; pc.dok[p][k] = fd.ok;
     }
     __syncthreads();
     for (int p = 0; p < np; ++p) {
@@ -1291,6 +1373,7 @@ __global__ __launch_bounds__(256) void pre_pack_kernel(const PreArgs a) {
         if (has) {                                                     // (uniform)
             const double* hq = a.histeq + ((size_t)b * 3 + p) * HEQ_STRIDE;
             for (int t = threadIdx.x; t < 512; t += 256) pc.heq[p][t] = hq[t];
+            if (threadIdx.x < 255) { const int j = threadIdx.x; pc.hslope[p][j] = (hq[256 + j + 1] - hq[256 + j]) / (hq[j + 1] - hq[j]); }
         }
         if (threadIdx.x == 0) {
             const double* hq = a.histeq + ((size_t)b * 3 + p) * HEQ_STRIDE;
@@ -1312,7 +1395,7 @@ __global__ __launch_bounds__(256) void pre_pack_kernel(const PreArgs a) {
             for (int c = 0; c < 3 && np > 0; ++c) {
                 if (np == 1 && c > 0) { ch[c] = ch[0]; continue; }
                 double w = raw;
-                for (int k = 0; k < pc.n[c]; ++k) w = apply_stage(pc.op[c][k], pc.q0[c][k], pc.q1[c][k], pc.par[c] + k * 4, pc.heq[c], w, pc.hinv[c]);
+                for (int k = 0; k < pc.n[c]; ++k) w = apply_stage_pack(pc, c, k, w);
                 ch[c] = w;
             }
             for (int c = 0; c < 3; ++c) v[c] = (float)ch[c] / 255.0f;

@@ -1045,6 +1045,12 @@ int cy_debug_stamps(unsigned long long* out8, int reset) {
     return CY_OK;
 }
 
+int cy_debug_fastdiv(const double* d_a, const double* d_b, double* d_fast, double* d_ref, int n) {
+    if (!d_a || !d_b || !d_fast || !d_ref || n < 1) return CY_ERR_ARG;
+    debug_fastdiv(d_a, d_b, d_fast, d_ref, n);
+    return hipGetLastError() == hipSuccess ? CY_OK : CY_ERR_HIP;
+}
+
 int cy_debug_cand_counts(cy_ctx* c, int* h_out, int B) {
     if (!c || !c->loaded || !h_out || B < 1 || B > c->cfg.max_batch) return fail(c, CY_ERR_ARG, "bad arguments");
     HIPCHK(c, hipDeviceSynchronize());

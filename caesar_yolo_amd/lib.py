@@ -18,7 +18,7 @@ EXPORTS = [
     "cy_create", "cy_destroy", "cy_last_error", "cy_load_weights", "cy_load_weights_mem", "cy_num_classes",
     "cy_weight_passes", "cy_class_name", "cy_plan_num_convs", "cy_plan_conv_desc", "cy_letterbox_geometry", "cy_num_anchors",
     "cy_pred_elems", "cy_profile_enable", "cy_profile_summary", "cy_profile_summary_lane", "cy_profile_layers", "cy_mosaic_prepare", "cy_letterbox_pack", "cy_preproc", "cy_preproc_planes", "cy_preproc_params", "cy_forward", "cy_debug_read_conv",
-    "cy_decode_nms", "cy_debug_stamps", "cy_debug_cand_counts", "cy_iou_merge", "cy_detect_tiles", "cy_detect_flush", "cy_detect_fence", "cy_compact_records", "cy_compact_records_ctx", "cy_detect_counters", "cy_conv_bn_silu", "cy_bottleneck64", "cy_make_tile_records",
+    "cy_decode_nms", "cy_debug_stamps", "cy_debug_fastdiv", "cy_debug_cand_counts", "cy_iou_merge", "cy_detect_tiles", "cy_detect_flush", "cy_detect_fence", "cy_compact_records", "cy_compact_records_ctx", "cy_detect_counters", "cy_conv_bn_silu", "cy_bottleneck64", "cy_make_tile_records",
     "cy_merge_edge_sources",
 ]
 
@@ -104,6 +104,7 @@ def load():
                                     vp, vp, vp, vp]),
         "cy_debug_cand_counts": (C.c_int, [vp, ip, C.c_int]),
         "cy_debug_stamps": (C.c_int, [C.POINTER(C.c_ulonglong), C.c_int]),
+        "cy_debug_fastdiv": (C.c_int, [vp, vp, vp, vp, C.c_int]),
         "cy_iou_merge": (C.c_int, [vp, vp, vp, C.c_int, C.c_float, C.c_double, C.c_double, vp, vp, vp, vp]),
         "cy_detect_tiles": (C.c_int, [vp, vp, C.c_int, C.c_int, ip, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.POINTER(cy_preproc_cfg), C.c_float, C.c_float, C.c_double, C.c_double,

@@ -133,6 +133,9 @@ int cy_decode_nms(cy_ctx* ctx, const float* d_pred, int B, int H, int W, int h0,
 
 /* developer diagnostics: in-kernel cycle stamps of the 3x3 halo kernel (enabled with CY_DBG=64) */
 int cy_debug_stamps(unsigned long long* out8, int reset);
+/* developer diagnostics: the pack kernel's quotient by a per-tile constant (d_fast) beside the float64 division (d_ref), element-wise on
+ * device arrays of n doubles: must agree bit for bit (tests/test_gpu_preproc.py) */
+int cy_debug_fastdiv(const double* d_a, const double* d_b, double* d_fast, double* d_ref, int n);
 /* number of pre-NMS candidates per tile of the last cy_decode_nms call (diagnostics) */
 int cy_debug_cand_counts(cy_ctx* ctx, int* h_out, int B);
 

@@ -317,3 +317,36 @@ def test_lean_passes_agree_with_the_general_ones(size, monkeypatch):
         np.testing.assert_array_equal(got[:, 2], base[:, 2], err_msg="HISTEQ channel, variant %d" % variant)
         np.testing.assert_allclose(got[:, :2], base[:, :2], rtol=1e-12, atol=1e-12, err_msg="sigma-clip channels, variant %d" % variant)
         np.testing.assert_allclose(det.preproc_params(len(xy)), par0, rtol=1e-12, atol=0, err_msg="solved parameters, variant %d" % variant)
+
+
+def test_fast_division_is_the_division():
+    """The pack kernel divides by per-tile constants with the tail of the float64 division's own instruction sequence (reciprocal and Newton
+    steps hoisted: csrc/cy_preproc.hip fast_div).  Same bits as `a / b` on 2^22 pairs over 60 decades, zeros, denormals, infinities and
+    exponents beyond the fast path's range (those take the division itself)."""
+    import ctypes as C
+    det = detector("fp32", max_imgsz=640)
+    rng = np.random.default_rng(20260105)
+    n = 1 << 22
+    a = rng.choice([-1.0, 1.0], n) * 10.0 ** rng.uniform(-30, 30, n)
+    b = rng.choice([-1.0, 1.0], n) * 10.0 ** rng.uniform(-30, 30, n)
+    a[:4096] = 0.0
+    a[4096:8192] *= 1e-290                                   # denormals and tiny values: the slow branch
+    a[8192:12288] *= 1e250
+    b[12288:16384] *= 1e200
+    b[16384:16400] = [0.0, -0.0, np.inf, -np.inf, np.nan, 5e-324, 1e-310, 1.7e308] * 2
+    a[16400:16416] = [np.inf, -np.inf, np.nan, 5e-324, -5e-324, 1e-310, 1.7e308, -1.7e308] * 2
+    # pixel-like operands: float32 values minus a float64 threshold, divided by a float64 range
+    a[100000:600000] = rng.normal(0, 1e-3, 500000).astype(np.float32).astype(np.float64) - rng.normal(0, 1e-3)
+    b[100000:600000] = rng.uniform(1e-4, 5e-2)
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    fast, ref = torch.empty_like(ta), torch.empty_like(ta)
+    rc = det.lib.cy_debug_fastdiv(C.c_void_p(ta.data_ptr()), C.c_void_p(tb.data_ptr()), C.c_void_p(fast.data_ptr()), C.c_void_p(ref.data_ptr()), n)
+    assert rc == 0
+    f, r = fast.cpu().numpy().view(np.uint64), ref.cpu().numpy().view(np.uint64)
+    nan = np.isnan(fast.cpu().numpy()) & np.isnan(ref.cpu().numpy())
+    bad = np.nonzero((f != r) & ~nan)[0]
+    assert bad.size == 0, "fast_div differs from a / b at %d of %d pairs, first: a=%r b=%r" % (bad.size, n, a[bad[0]], b[bad[0]])
+    with np.errstate(all="ignore"):
+        host = a / b
+    ok = np.isfinite(host)
+    assert np.array_equal(ref.cpu().numpy()[ok], host[ok])                # and the device division is IEEE (numpy's)
