@@ -350,3 +350,24 @@ def test_fast_division_is_the_division():
         host = a / b
     ok = np.isfinite(host)
     assert np.array_equal(ref.cpu().numpy()[ok], host[ok])                # and the device division is IEEE (numpy's)
+
+
+@pytest.mark.parametrize("pname", ["zscale_minmax", "chan3_minmax", "full"])
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+def test_specialised_pack_is_the_general_pack(pname, prec, monkeypatch):
+    """The pack kernel has forms specialised for the program shapes of the benchmarks (no per-stage switch; CY_PRE_VARIANT bit 8192 = the
+    general form for every shape): the packed network input must be identical, bit for bit."""
+    from caesar_yolo_amd import synth
+    det = detector(prec, max_imgsz=640)
+    mos = synth.make_mosaic(2048, seed=20260105)
+    size = 640
+    tiles = [np.ascontiguousarray(mos[y:y + size, x:x + size]) for (x, y) in [(0, 0), (1200, 900)]]
+    mosaic, xy = _mosaic(det, tiles)
+    cfg = PP.DataPreprocessor(PIPES[pname](PP)).program()
+    monkeypatch.setenv("CY_PRE_VARIANT", "8192")
+    ref, st0, _ = det.preproc(mosaic, xy, size, size, size, cfg)
+    ref = ref.clone()
+    monkeypatch.setenv("CY_PRE_VARIANT", "0")
+    got, st, _ = det.preproc(mosaic, xy, size, size, size, cfg)
+    assert st.cpu().tolist() == st0.cpu().tolist()
+    assert torch.equal(got, ref)
