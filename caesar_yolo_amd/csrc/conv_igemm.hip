@@ -451,6 +451,160 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_ige
     }
 }
 
+// ------------------------------------------------------------------------------------------------ detect-head output 1x1
+// The last convolution of each head branch (ultralytics Detect: cv2.x.2 = Conv2d(64, 4 * reg_max, 1), cv3.x.2 = Conv2d(c3, nc, 1);
+// no activation, fp32 rows of the prediction buffer) is a GEMM with K = 64..256 and <= 64 output channels: 1-4 K slabs, so the
+// generic 128 px x 64 ch tile spends its time in prologue, barriers and epilogue (35 TFLOP/s; the layer is HBM-bound at 0.4-0.5 KB
+// per pixel).  Here the WEIGHTS ARE STATIONARY: a workgroup copies the layer's whole packed filter (8-48 KB) to LDS once, in the
+// generic kernel's swizzled image, and its four waves then stream 32-pixel groups of the flattened batch (grid-stride over groups):
+// a lane loads its MFMA B operand -- 16 bytes of a pixel -- straight from global memory one K chunk ahead of the MFMAs that use
+// it, across group boundaries, so the request stream never drains; no barrier after the fill.
+// Per output value the MFMA chain is the generic kernel's (same instruction, same operands, same K order: chunks ascending, two
+// K steps of 32 each, fp16x3: the virtual chunks [x_lo | x_hi (| x_hi)]) and so is the epilogue: results are bit-identical
+// (tests/test_gpu_forward.py::test_head_output_kernel_is_bit_identical).  Rows of 16 packed weight rows that hold no real channel
+// (nc = 5: two of four) are neither copied nor multiplied.  nrows = 16 * (row groups kept).
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void head1x1_kernel(const ConvArgs a, const int nrows) {
+    constexpr int MI = 2, PG = 16 * MI, D = 4;              // D: K chunks in flight per wave (register ring)
+    constexpr int TP = 68;                                   // pitch (floats) of the store-transpose rows: conflict-free b128 writes and reads
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    const int M = a.B * a.Ho * a.Wo, HoWo = a.Ho * a.Wo, cpad = pad128(a.Cout);
+    const int pch = a.Cin / 64, vch = SPLIT ? a.split * pch : pch;
+    const int niv = nrows >> 4;
+    const bool tstore = a.Cout == 64;                        // whole 64-float slices: stores go through a per-wave LDS transpose
+    float* const tbuf = reinterpret_cast<float*>(smem + vch * nrows * 128) + wave * (PG * TP);
+
+    for (int i = tid; i < vch * nrows * 8; i += 256) {
+        const int q = i & 7, rr = i >> 3, r = rr % nrows, cc = rr / nrows;
+        const u32x4 w = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(a.wgt) + ((size_t)cc * cpad + r) * 128 + q * 16);
+        *reinterpret_cast<u32x4*>(smem + (cc * nrows + r) * 128 + ((q ^ (r & 7)) << 4)) = w;
+    }
+    __syncthreads();
+
+    const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in0), 0, a.in0_bytes, 0x00020000);
+    const int ngrp = (M + PG - 1) / PG, stride = gridDim.x * 4;
+    const int cbase = fq * 16;
+    float bv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) bv[j] = a.bias[cbase + j];
+    float sc[SPLIT ? 16 : 1];
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sc[j] = a.oscale[cbase + j];
+    }
+
+    u32x4 x[D][MI][2];
+    int gi = blockIdx.x * 4 + wave, vi = 0;                 // issue cursor (group, virtual chunk)
+    auto issue = [&](u32x4 (&xs)[MI][2]) {
+        if (gi >= ngrp) return;
+        int lo = 0;
+        const int ccp = SPLIT ? x3_chunk(vi, pch, lo) : vi;
+        const int lo0 = SPLIT && lo ? a.in0_lo : 0;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int m = gi * PG + mi * 16 + fr;
+            const unsigned base = (unsigned)(m * a.in0_ct + a.in0_coff + lo0 + ccp * 64 + fq * 8) * 2;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) xs[mi][kk] = load_b128(rs0, m < M ? base + kk * 64 : CY_OOB, 0);
+        }
+        if (++vi == vch) { vi = 0; gi += stride; }
+    };
+
+    f32x4 acc[4][MI];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int g = gi, v = 0;                                       // compute cursor
+    auto step = [&](u32x4 (&xc)[MI][2], u32x4 (&xn)[MI][2]) {
+        issue(xn);                                           // the slot the previous step consumed
+        const char* Wl = smem + v * nrows * 128;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int qf = fq + 4 * kk;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                if (ni < niv) {
+                    const int r = ni * 16 + fr;
+                    const f16x8 wb = *reinterpret_cast<const f16x8*>(Wl + r * 128 + ((qf ^ (r & 7)) << 4));
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb, __builtin_bit_cast(f16x8, xc[mi][kk]), acc[ni][mi], 0, 0, 0);
+                }
+            }
+        }
+        if (++v < vch) return;
+        v = 0;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int m = g * PG + mi * 16 + fr;
+            float o[16];
+            if constexpr (SPLIT) {
+                scale_bias_act16(acc[0][mi], acc[1][mi], acc[2][mi], acc[3][mi], bv, sc, false, o);
+            } else {
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[ni * 4 + j] = acc[ni][mi][j] + bv[ni * 4 + j];
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (tstore) {
+#pragma unroll
+                for (int j4 = 0; j4 < 4; ++j4)
+                    *reinterpret_cast<f32x4*>(tbuf + (mi * 16 + fr) * TP + cbase + 4 * j4) = f32x4{o[4 * j4], o[4 * j4 + 1], o[4 * j4 + 2], o[4 * j4 + 3]};
+                continue;
+            }
+            if (m >= M) continue;
+            const int b = m / HoWo, r = m - b * HoWo;
+            float* dst = reinterpret_cast<float*>(a.out) + ((long)b * a.out_bs + a.out_ro + r) * a.out_ct + a.out_coff + cbase;
+            if (cbase + 16 <= a.Cout) {
+                typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+#pragma unroll
+                for (int j4 = 0; j4 < 4; ++j4)
+                    *reinterpret_cast<f32x4u*>(dst + 4 * j4) = f32x4u{o[4 * j4], o[4 * j4 + 1], o[4 * j4 + 2], o[4 * j4 + 3]};
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if (cbase + j < a.Cout) dst[j] = o[j];
+            }
+        }
+        if (tstore) {
+            // wave-private transpose: a store instruction now covers four pixels' 256-byte slices (16 lanes x 16 bytes each) instead
+            // of 16-byte pieces of sixteen different rows
+            typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < PG / 4; ++i) {
+                const int px = 4 * i + fq, m = g * PG + px;
+                const f32x4 t = *reinterpret_cast<const f32x4*>(tbuf + px * TP + fr * 4);
+                if (m < M) {
+                    const int b = m / HoWo, r = m - b * HoWo;
+                    float* dst = reinterpret_cast<float*>(a.out) + ((long)b * a.out_bs + a.out_ro + r) * a.out_ct + a.out_coff + fr * 4;
+                    *reinterpret_cast<f32x4u*>(dst) = f32x4u{t[0], t[1], t[2], t[3]};
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the transpose rows are free again before the next group writes them
+        }
+        g += stride;
+    };
+
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) issue(x[d]);
+    while (true) {
+        if (g >= ngrp) break;
+        step(x[0], x[3]);
+        if (g >= ngrp) break;
+        step(x[1], x[0]);
+        if (g >= ngrp) break;
+        step(x[2], x[1]);
+        if (g >= ngrp) break;
+        step(x[3], x[2]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ 3x3 stride-1, halo reuse
 // 90 % of the network's FLOPs are 3x3 stride-1 convolutions.  As a plain implicit GEMM every filter tap re-fetches its
 // im2col rows, so a 128x128 tile moves 32 KB L2->LDS per 2.1 MFLOP (64 flop/B) and the kernel is bound by the L2->LDS
@@ -2830,6 +2984,30 @@ static hipError_t launch_t(const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// detect-head output 1x1 (head1x1_kernel): which layers it takes, and its launch.  Geometry only (no batch threshold).
+static int head_rows(const ConvArgs& a) { const int c = a.Cout < 16 ? a.Cout : 16; const int g = (c + 3) / 4; return 16 * (g < 4 ? g : 4); }
+static bool head_direct(const ConvArgs& a, int passes) {
+    if (!env_knob("CY_HEAD_DIRECT", 1)) return false;             // read per call: the parity tests run both forms
+    if (!(a.out_f32 && a.k == 1 && a.s == 1 && a.c1 == 0 && !a.up0 && !a.res && !a.act && a.Cin >= 64 && a.Cin % 64 == 0 && a.c0 == a.Cin &&
+          pad64(a.Cout) == 64 && a.Ho == a.Hi && a.Wo == a.Wi))
+        return false;
+    return (size_t)passes * (a.Cin / 64) * head_rows(a) * 128 <= 65536;
+}
+template <bool SPLIT>
+static hipError_t launch_head(const ConvArgs& a, hipStream_t s) {
+    const int nrows = head_rows(a);
+    const size_t lds = (size_t)(SPLIT ? a.split : 1) * (a.Cin / 64) * nrows * 128 + (a.Cout == 64 ? 4 * 32 * 68 * 4 : 0);     // weights + store transpose
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(head1x1_kernel<SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 4 * 32 * 68 * 4);
+        attr_set = true;
+    }
+    const long M = (long)a.B * a.Ho * a.Wo;
+    const long wgs = (M + 127) / 128;                             // one 32-pixel group per wave at least
+    hipLaunchKernelGGL((head1x1_kernel<SPLIT>), dim3((unsigned)(wgs < 1024 ? wgs : 1024)), dim3(256), lds, s, a, nrows);
+    return hipGetLastError();
+}
+
 // Kernel variants (also the keys of the profiling summary)
 static const char* const kVariantNames[CONV_NUM_VARIANTS] = {
     "conv_igemm_kernel<2,2,4> generic 128x128", "conv_igemm_kernel<4,1,2> generic 128x64",
@@ -2839,7 +3017,8 @@ static const char* const kVariantNames[CONV_NUM_VARIANTS] = {
     "conv3x3_wide_kernel 3x3 s1 16x32px x128ch, K slabs of 32",
     "conv1x1_direct_kernel<4,2> 1x1 256px x256ch, pixels to regs", "conv1x1_direct_kernel<2,2> 1x1 256px x128ch, pixels to regs",
     "conv3x3_wide_kernel<WN=1> 3x3 s1 16x32px x64ch", "conv3x3_wide_kernel<dual> 3x3 s1 2 images x 16x16px x128ch",
-    "conv3x3_widep_kernel<strip> 3x3 s1 512 flattened px x128ch, persistent"};
+    "conv3x3_widep_kernel<strip> 3x3 s1 512 flattened px x128ch, persistent",
+    "head1x1_kernel detect-head output 1x1, weights stationary in LDS, fp32 rows"};
 const char* conv_variant_name(int v) { return v >= 0 && v < CONV_NUM_VARIANTS ? kVariantNames[v] : "?"; }
 
 static bool s2_direct() { static const int v = getenv("CY_S2_DIRECT") ? atoi(getenv("CY_S2_DIRECT")) : 1; return v != 0; }
@@ -2872,6 +3051,7 @@ static int conv_variant_x3(const ConvArgs& a) {
     if (!a.out_f32 && a.Cin % 64 == 0 && !narrow &&
         ((a.k == 1 && a.s == 1 && (a.c1 == 0 || a.c0 % 64 == 0)) || (a.k == 3 && a.s == 2 && a.c1 == 0 && !a.up0)))
         return pad64(a.Cout) >= 256 ? CONV_DIRECT_256 : CONV_DIRECT_128;
+    if (head_direct(a, a.split)) return CONV_HEAD_1X1;
     return narrow ? CONV_GENERIC_64 : CONV_GENERIC_128;
 }
 
@@ -2918,6 +3098,7 @@ int conv_variant(Precision p, const ConvArgs& a) {
             return CONV_WIDE_DUAL;
         return CONV_HALO8_128;
     }
+    if (p == PREC_F16 && head_direct(a, 1)) return CONV_HEAD_1X1;
     if (narrow) return CONV_GENERIC_64;
     // 1x1: pixels-direct kernel once there is at least one 256-pixel tile per CU (below that the 128x128 tiles of the generic
     // kernel fill the chip better).  CY_DIRECT_MIN_BLOCKS is read per call so that the parity tests can force the path.
@@ -2949,6 +3130,7 @@ hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s) {
             case CONV_WIDE_DUAL: return launch_wide<2, true, 2, true>(a, s);
             case CONV_DIRECT_256: return a.k == 3 ? launch_direct<4, 2, 3, true, true>(a, s) : launch_direct<4, 2, 3, false, true>(a, s);
             case CONV_DIRECT_128: return a.k == 3 ? launch_direct<2, 4, 2, true, true>(a, s) : launch_direct<2, 2, 2, false, true>(a, s);
+            case CONV_HEAD_1X1: return launch_head<true>(a, s);
             case CONV_GENERIC_64: return launch_t<f16, 4, 1, 2, 2, true>(a, s);
             default: return launch_t<f16, 2, 2, 4, 2, true>(a, s);
         }
@@ -3004,6 +3186,7 @@ hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s) {
             // ahead) overlap each other's prologue/epilogue: -12 % against one workgroup with a 4-chunk ring
             if (a.k != 3 && !(getenv("CY_D128_V") && atoi(getenv("CY_D128_V")) == 0)) return launch_direct<2, 2, 2, false>(a, s);
             return a.k == 3 ? launch_direct<2, 4, 2, true>(a, s) : launch_direct<2, 2, 4, false>(a, s);
+        case CONV_HEAD_1X1: return launch_head<false>(a, s);
         case CONV_GENERIC_64: return p == PREC_F16 ? launch_t<f16, 4, 1, 2>(a, s) : launch_t<float, 4, 1, 2>(a, s);
         default: return p == PREC_F16 ? launch_t<f16, 2, 2, 4>(a, s) : launch_t<float, 2, 2, 4>(a, s);
     }

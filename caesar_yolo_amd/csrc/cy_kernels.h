@@ -107,7 +107,7 @@ hipError_t launch_dwconv(Precision p, const DwArgs& a, hipStream_t s);
 hipError_t launch_attention(Precision p, const AttnArgs& a, hipStream_t s);
 
 hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s);
-enum ConvVariant { CONV_GENERIC_128 = 0, CONV_GENERIC_64, CONV_HALO8_128, CONV_PP_64, CONV_PP_128, CONV_HALO16_128, CONV_C64_PERSIST, CONV_GENERIC_BIG, CONV_WIDE_128, CONV_DIRECT_256, CONV_DIRECT_128, CONV_WIDE_64, CONV_WIDE_DUAL, CONV_STRIP_128, CONV_NUM_VARIANTS };
+enum ConvVariant { CONV_GENERIC_128 = 0, CONV_GENERIC_64, CONV_HALO8_128, CONV_PP_64, CONV_PP_128, CONV_HALO16_128, CONV_C64_PERSIST, CONV_GENERIC_BIG, CONV_WIDE_128, CONV_DIRECT_256, CONV_DIRECT_128, CONV_WIDE_64, CONV_WIDE_DUAL, CONV_STRIP_128, CONV_HEAD_1X1, CONV_NUM_VARIANTS };
 int conv_variant(Precision p, const ConvArgs& a);          // which kernel launch_conv picks
 const char* conv_variant_name(int v);
 void debug_read_stamps(unsigned long long* out8, bool reset);

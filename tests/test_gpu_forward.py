@@ -257,3 +257,24 @@ def test_two_group_stem_kernel_is_bit_identical(shape, monkeypatch):
         got = det.forward(x)
         torch.cuda.synchronize()
         assert torch.equal(ref, got)
+
+
+@pytest.mark.parametrize("prec", ["fp16", "fp16x3"])
+def test_head_output_kernel_is_bit_identical(prec, monkeypatch):
+    """The weights-stationary kernel of the detect head's output 1x1s (head1x1_kernel: cv2.x.2 64 -> 64, cv3.x.2 256 -> nc,
+    fp32 prediction rows) against the generic implicit-GEMM kernel it replaces (CY_HEAD_DIRECT=0): the same MFMA chain per
+    output value, so the head output is bit-identical -- on square maps and on the ragged 416 x 512 letterbox shape whose
+    stride-32 map (13 x 16 x 3 tiles = 624 pixels) ends inside a 32-pixel group."""
+    det = detector(prec)
+    base = _tile("big512")
+    for imgs, size in (([_tile("big512", 256, 256), _tile("big512", 256, 256)[::-1].copy()], 256),
+                       ([base[:512, :394].copy(), base[:512, 100:494].copy(), base[:512, 118:512].copy()], 512)):
+        x, raw, _ = _oracle_forward(imgs, size)
+        xin = netin_from_chw(x, det.dtype)
+        monkeypatch.setenv("CY_HEAD_DIRECT", "0")
+        p0 = det.forward(xin).cpu().clone()
+        monkeypatch.setenv("CY_HEAD_DIRECT", "1")
+        p1 = det.forward(xin).cpu().clone()
+        assert torch.equal(p0, p1), "head output differs between the two kernels (%s, %d px): max %.3e" % (prec, size, float((p0 - p1).abs().max()))
+        tol = 6e-2 if prec == "fp16" else 2e-4
+        assert float((p1 - raw).abs().max()) <= tol * max(1.0, float(raw.abs().max()))
