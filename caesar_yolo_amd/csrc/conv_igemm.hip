@@ -605,6 +605,177 @@ __global__ __launch_bounds__(256) void head1x1_kernel(const ConvArgs a, const in
     }
 }
 
+// Both output convolutions of one stride level in ONE launch (default; CY_HEAD_PAIR=0: one launch each): a workgroup (8 waves) holds
+// both filters in LDS, a wave streams the K chunks of its 32 pixels from the box branch (64 channels) and then from the class
+// branch (256) through the same register ring, keeps two accumulator sets, and writes WHOLE prediction rows: the 64 + nc floats
+// of 16 pixels go through a wave-private LDS tile and leave as one contiguous run of dword stores (16 x 276 bytes for nc = 5)
+// instead of a 256-byte slice and a 20-byte slice per row from two kernels.  Same MFMA chains, same epilogue arithmetic: bit-identical.
+template <bool SPLIT>
+__global__ __launch_bounds__(512) void head1x1_pair_kernel(const ConvArgs a, const ConvArgs b, const int nrows_b, const int TP) {
+    constexpr int MI = 2, PG = 16 * MI, D = 4, NW = 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    const int M = a.B * a.Ho * a.Wo, HoWo = a.Ho * a.Wo;
+    const int pcha = a.Cin / 64, vcha = SPLIT ? a.split * pcha : pcha;
+    const int pchb = b.Cin / 64, vchb = SPLIT ? b.split * pchb : pchb;
+    const int vch = vcha + vchb, nivb = nrows_b >> 4, rowlen = a.out_ct;
+    char* const Wa = smem;
+    char* const Wb = smem + vcha * 64 * 128;
+    float* const tbuf = reinterpret_cast<float*>(Wb + vchb * nrows_b * 128) + wave * (16 * TP);
+
+    {
+        const int cpa = pad128(a.Cout), cpb = pad128(b.Cout);
+        for (int i = tid; i < vcha * 64 * 8; i += NW * 64) {
+            const int q = i & 7, rr = i >> 3, r = rr & 63, cc = rr >> 6;
+            const u32x4 w = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(a.wgt) + ((size_t)cc * cpa + r) * 128 + q * 16);
+            *reinterpret_cast<u32x4*>(Wa + (cc * 64 + r) * 128 + ((q ^ (r & 7)) << 4)) = w;
+        }
+        for (int i = tid; i < vchb * nrows_b * 8; i += NW * 64) {
+            const int q = i & 7, rr = i >> 3, r = rr % nrows_b, cc = rr / nrows_b;
+            const u32x4 w = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(b.wgt) + ((size_t)cc * cpb + r) * 128 + q * 16);
+            *reinterpret_cast<u32x4*>(Wb + (cc * nrows_b + r) * 128 + ((q ^ (r & 7)) << 4)) = w;
+        }
+    }
+    __syncthreads();
+
+    const auto rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in0), 0, a.in0_bytes, 0x00020000);
+    const auto rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(b.in0), 0, b.in0_bytes, 0x00020000);
+    const int ngrp = (M + PG - 1) / PG, stride = gridDim.x * NW;
+    const int cbase = fq * 16;
+    float bva[16], bvb[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { bva[j] = a.bias[cbase + j]; bvb[j] = b.bias[cbase + j]; }
+    float sca[SPLIT ? 16 : 1], scb[SPLIT ? 16 : 1];
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { sca[j] = a.oscale[cbase + j]; scb[j] = b.oscale[cbase + j]; }
+    }
+
+    u32x4 x[D][MI][2];
+    int gi = blockIdx.x * NW + wave, vi = 0;
+    auto issue = [&](u32x4 (&xs)[MI][2]) {
+        if (gi >= ngrp) return;
+        const bool sb = vi >= vcha;                          // wave-uniform: which branch this chunk belongs to
+        const int vv = sb ? vi - vcha : vi, pch = sb ? pchb : pcha;
+        int lo = 0;
+        const int ccp = SPLIT ? x3_chunk(vv, pch, lo) : vv;
+        const int ct = sb ? b.in0_ct : a.in0_ct, coff = sb ? b.in0_coff : a.in0_coff;
+        const int lo0 = SPLIT && lo ? (sb ? b.in0_lo : a.in0_lo) : 0;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int m = gi * PG + mi * 16 + fr;
+            const unsigned base = (unsigned)(m * ct + coff + lo0 + ccp * 64 + fq * 8) * 2;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const unsigned off = m < M ? base + kk * 64 : CY_OOB;
+                xs[mi][kk] = sb ? load_b128(rsb, off, 0) : load_b128(rsa, off, 0);
+            }
+        }
+        if (++vi == vch) { vi = 0; gi += stride; }
+    };
+
+    f32x4 acca[4][MI], accb[4][MI];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) { acca[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f}; accb[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    int g = gi, v = 0;
+    auto step = [&](u32x4 (&xc)[MI][2], u32x4 (&xn)[MI][2]) {
+        issue(xn);
+        if (v < vcha) {
+            const char* Wl = Wa + v * 64 * 128;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int qf = fq + 4 * kk;
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const int r = ni * 16 + fr;
+                    const f16x8 wb = *reinterpret_cast<const f16x8*>(Wl + r * 128 + ((qf ^ (r & 7)) << 4));
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+                        acca[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb, __builtin_bit_cast(f16x8, xc[mi][kk]), acca[ni][mi], 0, 0, 0);
+                }
+            }
+        } else {
+            const char* Wl = Wb + (v - vcha) * nrows_b * 128;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int qf = fq + 4 * kk;
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    if (ni < nivb) {
+                        const int r = ni * 16 + fr;
+                        const f16x8 wb = *reinterpret_cast<const f16x8*>(Wl + r * 128 + ((qf ^ (r & 7)) << 4));
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi)
+                            accb[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb, __builtin_bit_cast(f16x8, xc[mi][kk]), accb[ni][mi], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (++v < vch) return;
+        v = 0;
+        const int mg = g * PG;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            float oa[16], ob[16];
+            if constexpr (SPLIT) {
+                scale_bias_act16(acca[0][mi], acca[1][mi], acca[2][mi], acca[3][mi], bva, sca, false, oa);
+                scale_bias_act16(accb[0][mi], accb[1][mi], accb[2][mi], accb[3][mi], bvb, scb, false, ob);
+            } else {
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { oa[ni * 4 + j] = acca[ni][mi][j] + bva[ni * 4 + j]; ob[ni * 4 + j] = accb[ni][mi][j] + bvb[ni * 4 + j]; }
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) { acca[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f}; accb[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            float* trow = tbuf + fr * TP;
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4)
+                *reinterpret_cast<f32x4*>(trow + cbase + 4 * j4) = f32x4{oa[4 * j4], oa[4 * j4 + 1], oa[4 * j4 + 2], oa[4 * j4 + 3]};
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (cbase + j < b.Cout) trow[64 + cbase + j] = ob[j];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // 16 whole rows: one contiguous run in the prediction buffer unless the run crosses into the next image
+            const int m0 = mg + mi * 16;
+            const int npx = M - m0 < 16 ? M - m0 : 16;
+            if (npx > 0) {
+                const int b0 = m0 / HoWo, r0 = m0 - b0 * HoWo;
+                float* const obase = reinterpret_cast<float*>(a.out);
+                const int nit = (16 * rowlen + 63) >> 6;
+                int px = 0, c = lane;
+                for (int i = 0; i < nit; ++i) {
+                    if (px < npx) {
+                        int r = r0 + px, bb = b0;
+                        while (r >= HoWo) { r -= HoWo; ++bb; }
+                        obase[((long)bb * a.out_bs + a.out_ro + r) * rowlen + c] = tbuf[px * TP + c];
+                    }
+                    c += 64;
+                    if (c >= rowlen) { c -= rowlen; ++px; }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        g += stride;
+    };
+
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) issue(x[d]);
+    while (true) {
+        if (g >= ngrp) break;
+        step(x[0], x[3]);
+        if (g >= ngrp) break;
+        step(x[1], x[0]);
+        if (g >= ngrp) break;
+        step(x[2], x[1]);
+        if (g >= ngrp) break;
+        step(x[3], x[2]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ 3x3 stride-1, halo reuse
 // 90 % of the network's FLOPs are 3x3 stride-1 convolutions.  As a plain implicit GEMM every filter tap re-fetches its
 // im2col rows, so a 128x128 tile moves 32 KB L2->LDS per 2.1 MFLOP (64 flop/B) and the kernel is bound by the L2->LDS
@@ -3005,6 +3176,36 @@ static hipError_t launch_head(const ConvArgs& a, hipStream_t s) {
     const long M = (long)a.B * a.Ho * a.Wo;
     const long wgs = (M + 127) / 128;                             // one 32-pixel group per wave at least
     hipLaunchKernelGGL((head1x1_kernel<SPLIT>), dim3((unsigned)(wgs < 1024 ? wgs : 1024)), dim3(256), lds, s, a, nrows);
+    return hipGetLastError();
+}
+
+// the two output convolutions of a stride level as one launch (head1x1_pair_kernel): a = box branch (64 channels at column 0),
+// b = class branch (nc channels at column 64) of the same pixels and prediction rows
+static int head_pair_pitch(int rowlen) { int tp = rowlen; while (tp % 8 != 4) ++tp; return tp; }      // conflict-free b128 rows
+static size_t head_pair_lds(Precision p, const ConvArgs& a, const ConvArgs& b) {
+    const size_t pa = p == PREC_F16X3 ? a.split : 1, pb = p == PREC_F16X3 ? b.split : 1;
+    return pa * (a.Cin / 64) * 64 * 128 + pb * (b.Cin / 64) * head_rows(b) * 128 + (size_t)8 * 16 * head_pair_pitch(a.out_ct) * 4;
+}
+bool head_pair_ok(Precision p, const ConvArgs& a, const ConvArgs& b) {
+    if (p == PREC_F32 || !env_knob("CY_HEAD_PAIR", 1)) return false;       // read per call: the parity tests run both forms
+    if (conv_variant(p, a) != CONV_HEAD_1X1 || conv_variant(p, b) != CONV_HEAD_1X1) return false;
+    if (a.B != b.B || a.Ho != b.Ho || a.Wo != b.Wo || a.out != b.out || a.out_ct != b.out_ct || a.out_bs != b.out_bs || a.out_ro != b.out_ro) return false;
+    if (a.out_coff != 0 || a.Cout != 64 || b.out_coff != 64 || b.Cout < 1 || b.Cout != a.out_ct - 64) return false;
+    return head_pair_lds(p, a, b) <= 128 * 1024;
+}
+hipError_t launch_head_pair(Precision p, const ConvArgs& a, const ConvArgs& b, hipStream_t s) {
+    const size_t lds = head_pair_lds(p, a, b);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(head1x1_pair_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(head1x1_pair_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        attr_set = true;
+    }
+    const long M = (long)a.B * a.Ho * a.Wo;
+    const long wgs = (M + 255) / 256;                             // one 32-pixel group per wave at least
+    const unsigned grid = (unsigned)(wgs < 512 ? wgs : 512);
+    if (p == PREC_F16X3) hipLaunchKernelGGL((head1x1_pair_kernel<true>), dim3(grid), dim3(512), lds, s, a, b, head_rows(b), head_pair_pitch(a.out_ct));
+    else hipLaunchKernelGGL((head1x1_pair_kernel<false>), dim3(grid), dim3(512), lds, s, a, b, head_rows(b), head_pair_pitch(a.out_ct));
     return hipGetLastError();
 }
 

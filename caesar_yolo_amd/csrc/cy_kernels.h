@@ -110,6 +110,9 @@ hipError_t launch_conv(Precision p, const ConvArgs& a, hipStream_t s);
 enum ConvVariant { CONV_GENERIC_128 = 0, CONV_GENERIC_64, CONV_HALO8_128, CONV_PP_64, CONV_PP_128, CONV_HALO16_128, CONV_C64_PERSIST, CONV_GENERIC_BIG, CONV_WIDE_128, CONV_DIRECT_256, CONV_DIRECT_128, CONV_WIDE_64, CONV_WIDE_DUAL, CONV_STRIP_128, CONV_HEAD_1X1, CONV_NUM_VARIANTS };
 int conv_variant(Precision p, const ConvArgs& a);          // which kernel launch_conv picks
 const char* conv_variant_name(int v);
+// the two output 1x1s of a detect-head level (box branch a, class branch b) in one launch of head1x1_pair_kernel (conv_igemm.hip)
+bool head_pair_ok(Precision p, const ConvArgs& a, const ConvArgs& b);
+hipError_t launch_head_pair(Precision p, const ConvArgs& a, const ConvArgs& b, hipStream_t s);
 void debug_read_stamps(unsigned long long* out8, bool reset);
 void debug_read_wg_stamps(unsigned long long* out, int n);      // raw per-workgroup phase records (n x 4), stamped builds   // developer diagnostics (CY_DBG=64)
 void debug_read_pre_stamps(unsigned long long* out8, bool reset);

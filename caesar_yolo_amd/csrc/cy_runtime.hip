@@ -698,6 +698,8 @@ static int forward_on(cy_ctx* c, const void* d_netin, int B, int H, int W, float
     c->pw_fused_conv = -1;
     const int pw_env = env_knob("CY_FUSE_PW", 1);             // back-to-back pairs (pw_pair); read per call: the parity tests run both forms
 
+    struct HeadPend { ConvArgs a; double flops; int conv; bool on; };
+    HeadPend pend[3] = {};                                    // deferred box-branch output convolutions, per stride level
     const int bneck_env = env_knob("CY_BNECK_FUSE", 0);       // off by default (slower than two launches so far, see bneck64.hip); read per call: the parity tests run both forms
     auto run_op = [&](const Op& o, const Op* next, int b0, int Bn, bool* fused) -> int {
         auto tp = [&](int t) -> char* {                    // tensor base for images [b0, b0+Bn)
@@ -820,6 +822,25 @@ static int forward_on(cy_ctx* c, const void* d_netin, int B, int H, int W, float
                 flops += 2.0 * Bn * a.Ho * a.Wo * (double)d2.cout * d2.cin;
                 *fused = true; c->pw_fused_conv = o.conv;
             }
+            // the two output convolutions of a detect-head level (box branch at column 0, class branch at column 64 of the same
+            // prediction rows) as ONE launch: the box branch's launch is deferred until the class branch's arguments are known
+            // (nothing else reads the prediction rows inside the forward pass); CY_HEAD_PAIR=0 / other shapes: one launch each
+            if (o.out < 0 && o.pred_coff == 0 && c->prec != PREC_F32 && env_knob("CY_HEAD_PAIR", 1) && conv_variant(c->prec, a) == CONV_HEAD_1X1) {
+                HeadPend& h = pend[o.pred_level];
+                if (h.on) { cur_conv = h.conv; HIPCHK(c, launch_conv(c->prec, h.a, s)); prof_done(conv_variant(c->prec, h.a), h.flops); cur_conv = o.conv; }
+                h.a = a; h.flops = flops; h.conv = o.conv; h.on = true;
+                return CY_OK;
+            }
+            if (o.out < 0 && o.pred_coff == 64 && pend[o.pred_level].on) {
+                HeadPend& h = pend[o.pred_level];
+                h.on = false;
+                if (head_pair_ok(c->prec, h.a, a)) {
+                    HIPCHK(c, launch_head_pair(c->prec, h.a, a, s));
+                    prof_done(CONV_HEAD_1X1, flops + h.flops);
+                    return CY_OK;
+                }
+                cur_conv = h.conv; HIPCHK(c, launch_conv(c->prec, h.a, s)); prof_done(conv_variant(c->prec, h.a), h.flops); cur_conv = o.conv;
+            }
             HIPCHK(c, launch_conv(c->prec, a, s));
             prof_done(conv_variant(c->prec, a), flops);
         }
@@ -838,7 +859,10 @@ static int forward_on(cy_ctx* c, const void* d_netin, int B, int H, int W, float
         const int Bn = B - b0 < sub ? B - b0 : sub;
         rc = run_range(0, n_head, b0, Bn); if (rc) return rc;
     }
-    return run_range(n_head, p.ops.size(), 0, B);
+    rc = run_range(n_head, p.ops.size(), 0, B); if (rc) return rc;
+    for (HeadPend& h : pend)                                  // a box branch whose class branch never came (no such plan today)
+        if (h.on) { h.on = false; cur_conv = h.conv; HIPCHK(c, launch_conv(c->prec, h.a, s)); prof_done(conv_variant(c->prec, h.a), h.flops); }
+    return CY_OK;
 }
 
 int cy_profile_enable(cy_ctx* c, int on) {

@@ -261,10 +261,12 @@ def test_two_group_stem_kernel_is_bit_identical(shape, monkeypatch):
 
 @pytest.mark.parametrize("prec", ["fp16", "fp16x3"])
 def test_head_output_kernel_is_bit_identical(prec, monkeypatch):
-    """The weights-stationary kernel of the detect head's output 1x1s (head1x1_kernel: cv2.x.2 64 -> 64, cv3.x.2 256 -> nc,
-    fp32 prediction rows) against the generic implicit-GEMM kernel it replaces (CY_HEAD_DIRECT=0): the same MFMA chain per
-    output value, so the head output is bit-identical -- on square maps and on the ragged 416 x 512 letterbox shape whose
-    stride-32 map (13 x 16 x 3 tiles = 624 pixels) ends inside a 32-pixel group."""
+    """The weights-stationary kernels of the detect head's output 1x1s (cv2.x.2 64 -> 64, cv3.x.2 256 -> nc, fp32 prediction
+    rows) against the generic implicit-GEMM kernel they replace (CY_HEAD_DIRECT=0): one launch per layer (head1x1_kernel,
+    CY_HEAD_PAIR=0) and the default, both layers of a level in one launch that writes whole prediction rows
+    (head1x1_pair_kernel).  The same MFMA chain per output value, so the head output is bit-identical -- on square maps and on the
+    ragged 416 x 512 letterbox shape whose stride-32 map (13 x 16 pixels x 3 tiles = 624 pixels) ends inside a 32-pixel group and
+    whose 16-row runs cross image boundaries."""
     det = detector(prec)
     base = _tile("big512")
     for imgs, size in (([_tile("big512", 256, 256), _tile("big512", 256, 256)[::-1].copy()], 256),
@@ -274,7 +276,11 @@ def test_head_output_kernel_is_bit_identical(prec, monkeypatch):
         monkeypatch.setenv("CY_HEAD_DIRECT", "0")
         p0 = det.forward(xin).cpu().clone()
         monkeypatch.setenv("CY_HEAD_DIRECT", "1")
+        monkeypatch.setenv("CY_HEAD_PAIR", "0")
         p1 = det.forward(xin).cpu().clone()
-        assert torch.equal(p0, p1), "head output differs between the two kernels (%s, %d px): max %.3e" % (prec, size, float((p0 - p1).abs().max()))
+        monkeypatch.delenv("CY_HEAD_PAIR")
+        p2 = det.forward(xin).cpu().clone()
+        assert torch.equal(p0, p1), "one launch per layer vs generic (%s, %d px): max %.3e" % (prec, size, float((p0 - p1).abs().max()))
+        assert torch.equal(p0, p2), "one launch per level vs generic (%s, %d px): max %.3e" % (prec, size, float((p0 - p2).abs().max()))
         tol = 6e-2 if prec == "fp16" else 2e-4
-        assert float((p1 - raw).abs().max()) <= tol * max(1.0, float(raw.abs().max()))
+        assert float((p2 - raw).abs().max()) <= tol * max(1.0, float(raw.abs().max()))
