@@ -3601,6 +3601,84 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemArgs a) {
     }
 }
 
+// The same layer with FOUR horizontally adjacent output pixels per thread (maps whose width is a multiple of 4): the form above reads
+// every weight from LDS for a single FMA and is bound by that (16-byte LDS reads for 4 lanes' worth of FMAs: 20 TFLOP/s of fp32 in the
+// fp16x3 context, 4.9 % of its forward pass); here a weight read feeds four pixels, and the four pixels' 3 x 9 input columns are loaded
+// once (27 loads instead of 36).  Per output value the FMA chain is the one above (taps ascending, fmaf), so results are bit-identical
+// (tests/test_gpu_forward.py::test_stem_four_pixel_form_is_bit_identical).  CY_STEM_QUAD=0: the form above.
+template <typename T, bool SPLIT = false>
+__global__ __launch_bounds__(256) void stem_quad_kernel(const StemArgs a) {
+    __shared__ __attribute__((aligned(16))) float w[27 * 64];
+    __shared__ float bs[64];
+    const int co_blocks = a.Cout / 16, wq = a.Wo >> 2;
+    for (int i = threadIdx.x; i < 27 * a.Cout; i += 256) w[i] = a.w[i];
+    for (int i = threadIdx.x; i < a.Cout; i += 256) bs[i] = a.bias[i];
+    __syncthreads();
+    const long total = (long)a.B * a.Ho * wq * co_blocks;
+    typedef T vec4 __attribute__((ext_vector_type(4)));
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int cb = (int)(idx % co_blocks);
+        const long q = idx / co_blocks;
+        const int wo0 = (int)(q % wq) * 4;
+        const int ho = (int)((q / wq) % a.Ho);
+        const int b = (int)(q / ((long)wq * a.Ho));
+        float acc[4][16];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[p][j] = 0.0f;
+#pragma unroll 1
+        for (int kh = 0; kh < 3; ++kh) {
+            const int hi = ho * 2 - 1 + kh;
+            const bool row_ok = (unsigned)hi < (unsigned)a.Hi;
+            vec4 r[9];
+#pragma unroll
+            for (int ci = 0; ci < 9; ++ci) {
+                const int wi = wo0 * 2 - 1 + ci;
+                r[ci] = vec4{(T)0, (T)0, (T)0, (T)0};
+                if (row_ok && (unsigned)wi < (unsigned)a.Wi)
+                    r[ci] = *reinterpret_cast<const vec4*>(reinterpret_cast<const T*>(a.in) + (((long)b * a.Hi + hi) * a.Wi + wi) * 4);
+            }
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    asm volatile("" ::: "memory");           // weights of one tap at a time (hoisted, all 432 of them would live in registers)
+                    const float* wr = w + ((kh * 3 + kw) * 3 + c) * a.Cout + cb * 16;
+                    float wv[16];
+#pragma unroll
+                    for (int j4 = 0; j4 < 4; ++j4) {
+                        const f32x4 t4 = *reinterpret_cast<const f32x4*>(wr + 4 * j4);
+                        wv[4 * j4] = t4[0]; wv[4 * j4 + 1] = t4[1]; wv[4 * j4 + 2] = t4[2]; wv[4 * j4 + 3] = t4[3];
+                    }
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const float xv = (float)r[2 * p + kw][c];
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) acc[p][j] = fmaf(xv, wv[j], acc[p][j]);
+                    }
+                }
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const long pix = ((long)b * a.Ho + ho) * a.Wo + wo0 + p;
+            if constexpr (SPLIT) {
+                float v16[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) v16[j] = silu_fast(acc[p][j] + bs[cb * 16 + j]);
+                store_split16(reinterpret_cast<f16*>(a.out) + pix * a.out_ct + a.out_coff + cb * 16, a.out_lo, v16);
+            } else {
+                T* dst = reinterpret_cast<T*>(a.out) + pix * a.out_ct + a.out_coff + cb * 16;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const float v = acc[p][j] + bs[cb * 16 + j];
+                    dst[j] = (T)((sizeof(T) == 2) ? silu_fast(v) : silu_exact(v));
+                }
+            }
+        }
+    }
+}
+
 // fp16 context: the stem as a K=32 (27 padded) MFMA GEMM.  A wave turns 16 output pixels x 64 channels per step:
 // the 64x32 weight panel lives in registers for the whole kernel (A operand), each lane gathers the 8 im2col values of
 // its (pixel, k-chunk) from the NHWC4 image with the halo zeroed, and stores 16 contiguous channels of its pixel.
@@ -3670,6 +3748,13 @@ hipError_t launch_stem(Precision p, const StemArgs& a, hipStream_t s) {
         const long ngroups = ((long)a.B * a.Ho * a.Wo + 15) / 16;
         const int grid = (int)((ngroups + 3) / 4 < 4096 ? (ngroups + 3) / 4 : 4096);
         hipLaunchKernelGGL(stem_mfma_kernel, dim3(grid), dim3(256), 0, s, a, reinterpret_cast<const f16*>(a.wpk));
+        return hipGetLastError();
+    }
+    if (p != PREC_F16 && a.Wo % 4 == 0 && env_knob("CY_STEM_QUAD", 1)) {      // four pixels per thread (bit-identical; read per call: tests)
+        const long total4 = (long)a.B * a.Ho * (a.Wo / 4) * (a.Cout / 16);
+        const int grid4 = (int)((total4 + 255) / 256 < 16384 ? (total4 + 255) / 256 : 16384);
+        if (p == PREC_F16X3) hipLaunchKernelGGL((stem_quad_kernel<float, true>), dim3(grid4), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(stem_quad_kernel<float>, dim3(grid4), dim3(256), 0, s, a);
         return hipGetLastError();
     }
     const long total = (long)a.B * a.Ho * a.Wo * (a.Cout / 16);

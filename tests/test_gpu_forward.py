@@ -284,3 +284,25 @@ def test_head_output_kernel_is_bit_identical(prec, monkeypatch):
         assert torch.equal(p0, p2), "one launch per level vs generic (%s, %d px): max %.3e" % (prec, size, float((p0 - p2).abs().max()))
         tol = 6e-2 if prec == "fp16" else 2e-4
         assert float((p2 - raw).abs().max()) <= tol * max(1.0, float(raw.abs().max()))
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16x3"])
+def test_stem_four_pixel_form_is_bit_identical(prec, monkeypatch):
+    """model.0 in the fp32 / fp16x3 contexts (exact fp32 FMA chain, K = 27): four output pixels per thread (stem_quad_kernel,
+    default on maps whose width is a multiple of 4) against one pixel per thread (CY_STEM_QUAD=0) -- the same chain per output
+    value, so model.0 and the head output are bit-identical; both within the context's tolerance of the oracle."""
+    det = detector(prec)
+    imgs = [_tile("big512", 256, 256), _tile("big512", 256, 256)[::-1].copy()]
+    x, raw, taps = _oracle_forward(imgs, 256)
+    xin = netin_from_chw(x, det.dtype)
+    ref = taps["model.0"]
+    monkeypatch.setenv("CY_STEM_QUAD", "0")
+    p0 = det.forward(xin).cpu().clone()
+    t0 = torch.from_numpy(det.read_conv("model.0", ref.numel()))
+    monkeypatch.setenv("CY_STEM_QUAD", "1")
+    p1 = det.forward(xin).cpu().clone()
+    t1 = torch.from_numpy(det.read_conv("model.0", ref.numel()))
+    assert torch.equal(t0, t1), "model.0 differs: max %.3e" % float((t0 - t1).abs().max())
+    assert torch.equal(p0, p1)
+    assert float((t1 - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
+    assert float((p1 - raw).abs().max()) <= 2e-4 * max(1.0, float(raw.abs().max()))
