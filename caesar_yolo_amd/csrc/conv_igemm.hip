@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256) void head1x1_kernel(const ConvArgs a, const in
     const int M = a.B * a.Ho * a.Wo, HoWo = a.Ho * a.Wo, cpad = pad128(a.Cout);
     const int pch = a.Cin / 64, vch = SPLIT ? a.split * pch : pch;
     const int niv = nrows >> 4;
-    const bool tstore = a.Cout == 64;                        // whole 64-float slices: stores go through a per-wave LDS transpose
+    const bool tstore = a.Cout == 64 && a.out_f32;           // whole 64-float slices: stores go through a per-wave LDS transpose
     float* const tbuf = reinterpret_cast<float*>(smem + vch * nrows * 128) + wave * (PG * TP);
 
     for (int i = tid; i < vch * nrows * 8; i += 256) {
@@ -542,15 +542,62 @@ __global__ __launch_bounds__(256) void head1x1_kernel(const ConvArgs a, const in
             const int m = g * PG + mi * 16 + fr;
             float o[16];
             if constexpr (SPLIT) {
-                scale_bias_act16(acc[0][mi], acc[1][mi], acc[2][mi], acc[3][mi], bv, sc, false, o);
+                scale_bias_act16(acc[0][mi], acc[1][mi], acc[2][mi], acc[3][mi], bv, sc, a.act != 0, o);
             } else {
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[ni * 4 + j] = acc[ni][mi][j] + bv[ni * 4 + j];
+                    for (int j = 0; j < 4; ++j) {
+                        float xo = acc[ni][mi][j] + bv[ni * 4 + j];
+                        if (a.act) xo = silu_fast(xo);
+                        o[ni * 4 + j] = xo;
+                    }
             }
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!a.out_f32) {
+                // narrow 1x1 layers inside the network (YOLO11 C3k branches, small YOLOv8 scales): fp16 (or high / low halves) into a
+                // channel slice, optional residual -- the generic kernel's epilogue, value for value
+                if (m >= M) continue;
+                f16* dst = reinterpret_cast<f16*>(a.out) + (long)m * a.out_ct + a.out_coff + cbase;
+                const f16* rp = a.res ? reinterpret_cast<const f16*>(a.res) + (long)m * a.res_ct + a.res_coff + cbase : nullptr;
+                if (cbase + 16 <= a.Cout) {
+                    if (rp) {
+                        const f16x8 r0v = *reinterpret_cast<const f16x8*>(rp), r1v = *reinterpret_cast<const f16x8*>(rp + 8);
+                        if constexpr (SPLIT) {
+                            const f16x8 q0v = *reinterpret_cast<const f16x8*>(rp + a.res_lo), q1v = *reinterpret_cast<const f16x8*>(rp + a.res_lo + 8);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) { o[j] += (float)r0v[j] + (float)q0v[j]; o[8 + j] += (float)r1v[j] + (float)q1v[j]; }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) { o[j] += (float)r0v[j]; o[8 + j] += (float)r1v[j]; }
+                        }
+                    }
+                    if constexpr (SPLIT) {
+                        store_split16(dst, a.out_lo, o);
+                    } else {
+                        f16x8 o0, o1;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { o0[j] = (f16)o[j]; o1[j] = (f16)o[8 + j]; }
+                        *reinterpret_cast<f16x8*>(dst) = o0;
+                        *reinterpret_cast<f16x8*>(dst + 8) = o1;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        if (cbase + j >= a.Cout) continue;
+                        float xo = o[j];
+                        if constexpr (SPLIT) {
+                            if (rp) xo += (float)rp[j] + (float)rp[a.res_lo + j];
+                            store_split1(dst + j, a.out_lo, xo);
+                        } else {
+                            if (rp) xo += (float)rp[j];
+                            dst[j] = (f16)xo;
+                        }
+                    }
+                }
+                continue;
+            }
             if (tstore) {
 #pragma unroll
                 for (int j4 = 0; j4 < 4; ++j4)
@@ -3159,15 +3206,15 @@ static hipError_t launch_t(const ConvArgs& a, hipStream_t s) {
 static int head_rows(const ConvArgs& a) { const int c = a.Cout < 16 ? a.Cout : 16; const int g = (c + 3) / 4; return 16 * (g < 4 ? g : 4); }
 static bool head_direct(const ConvArgs& a, int passes) {
     if (!env_knob("CY_HEAD_DIRECT", 1)) return false;             // read per call: the parity tests run both forms
-    if (!(a.out_f32 && a.k == 1 && a.s == 1 && a.c1 == 0 && !a.up0 && !a.res && !a.act && a.Cin >= 64 && a.Cin % 64 == 0 && a.c0 == a.Cin &&
-          pad64(a.Cout) == 64 && a.Ho == a.Hi && a.Wo == a.Wi))
+    if (!(a.k == 1 && a.s == 1 && a.c1 == 0 && !a.up0 && a.Cin >= 64 && a.Cin % 64 == 0 && a.c0 == a.Cin && pad64(a.Cout) == 64 && a.Ho == a.Hi && a.Wo == a.Wi))
         return false;
+    if (a.out_f32 ? (a.res || a.act) : (a.out_bs != a.Ho * a.Wo || a.out_ro != 0 || !env_knob("CY_NARROW_DIRECT", 1))) return false;      // head rows: no residual / activation; inside the network: plain pixel order
     return (size_t)passes * (a.Cin / 64) * head_rows(a) * 128 <= 65536;
 }
 template <bool SPLIT>
 static hipError_t launch_head(const ConvArgs& a, hipStream_t s) {
     const int nrows = head_rows(a);
-    const size_t lds = (size_t)(SPLIT ? a.split : 1) * (a.Cin / 64) * nrows * 128 + (a.Cout == 64 ? 4 * 32 * 68 * 4 : 0);     // weights + store transpose
+    const size_t lds = (size_t)(SPLIT ? a.split : 1) * (a.Cin / 64) * nrows * 128 + (a.Cout == 64 && a.out_f32 ? 4 * 32 * 68 * 4 : 0);     // weights + store transpose
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(head1x1_kernel<SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 4 * 32 * 68 * 4);

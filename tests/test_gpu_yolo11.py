@@ -157,3 +157,27 @@ def test_malformed_cyw2_plan_is_refused(tmp_path, field, delta):
     W.write_cyw2(path, g, [(cs, wd[cs.name][0], wd[cs.name][1]) for cs in g.convs], {0: "a", 1: "b", 2: "c"})
     with pytest.raises(L.CyError, match="malformed CYW2 plan"):
         HipDetector(path, device=0, precision="fp16", max_batch=1, max_imgsz=64)
+
+
+@pytest.mark.parametrize("scale,prec", [("l", "fp16"), ("l", "fp16x3"), ("n", "fp16")])
+def test_narrow_1x1_layers_on_the_streaming_kernel_are_bit_identical(tmp_path, scale, prec, monkeypatch):
+    """1x1 convolutions with <= 64 output channels inside the network (YOLO11l: the C3k branches of model.2 / model.4, 64 -> 32 and
+    64 -> 64 with SiLU, fp16 or high / low halves into channel slices) run on the weights-stationary streaming kernel of the detect
+    head (head1x1_kernel) instead of the generic 128 px x 64 ch tile; CY_NARROW_DIRECT=0 keeps the generic kernel.  Same MFMA chain
+    and epilogue per value: the head output is bit-identical."""
+    from caesar_yolo_amd import weights as W
+    from caesar_yolo_amd.model import HipDetector
+    g, wd = seeded_folded(scale, 3)
+    path = str(tmp_path / ("y11%s.cyw" % scale))
+    W.write_cyw2(path, g, [(cs, wd[cs.name][0], wd[cs.name][1]) for cs in g.convs], {0: "a", 1: "b", 2: "c"})
+    det = HipDetector(path, device=0, precision=prec, max_batch=3, max_imgsz=256)
+    rng = np.random.default_rng(7)
+    x = torch.from_numpy(rng.uniform(0, 1, (3, 3, 256, 192)).astype(np.float32))
+    xin = netin_from_chw(x, det.dtype)
+    monkeypatch.setenv("CY_NARROW_DIRECT", "0")
+    p0 = det.forward(xin).cpu().clone()
+    monkeypatch.setenv("CY_NARROW_DIRECT", "1")
+    p1 = det.forward(xin).cpu().clone()
+    assert torch.isfinite(p1).all()
+    assert torch.equal(p0, p1), "max difference %.3e" % float((p0 - p1).abs().max())
+    det.close()
