@@ -3222,7 +3222,7 @@ static hipError_t launch_head(const ConvArgs& a, hipStream_t s) {
     }
     const long M = (long)a.B * a.Ho * a.Wo;
     const long wgs = (M + 127) / 128;                             // one 32-pixel group per wave at least
-    hipLaunchKernelGGL((head1x1_kernel<SPLIT>), dim3((unsigned)(wgs < 1024 ? wgs : 1024)), dim3(256), lds, s, a, nrows);
+    hipLaunchKernelGGL((head1x1_kernel<SPLIT>), dim3((unsigned)(wgs < 512 ? wgs : 512)), dim3(256), lds, s, a, nrows);      // persistent: two 4-wave workgroups per CU
     return hipGetLastError();
 }
 
@@ -3250,7 +3250,7 @@ hipError_t launch_head_pair(Precision p, const ConvArgs& a, const ConvArgs& b, h
     }
     const long M = (long)a.B * a.Ho * a.Wo;
     const long wgs = (M + 255) / 256;                             // one 32-pixel group per wave at least
-    const unsigned grid = (unsigned)(wgs < 512 ? wgs : 512);
+    const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);           // persistent: one 8-wave workgroup per CU is what the register file holds
     if (p == PREC_F16X3) hipLaunchKernelGGL((head1x1_pair_kernel<true>), dim3(grid), dim3(512), lds, s, a, b, head_rows(b), head_pair_pitch(a.out_ct));
     else hipLaunchKernelGGL((head1x1_pair_kernel<false>), dim3(grid), dim3(512), lds, s, a, b, head_rows(b), head_pair_pitch(a.out_ct));
     return hipGetLastError();
