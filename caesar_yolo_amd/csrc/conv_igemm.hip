@@ -4232,7 +4232,8 @@ __global__ __launch_bounds__(256) void pool5_kernel(const PoolArgs a) {
     typedef T vec __attribute__((ext_vector_type(V)));
     const int cv = a.C / V;
     const long total = (long)a.B * a.H * a.W * cv;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    // (single-pass launch; workgroups in XCD-contiguous order: the 5 x 5 windows of neighbouring rows meet in one L2)
+    for (long idx = (long)xcd_contiguous(blockIdx.x, gridDim.x) * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int c = (int)(idx % cv) * V;
         const long pix = idx / cv;
         const int w = (int)(pix % a.W), h = (int)((pix / a.W) % a.H), b = (int)(pix / ((long)a.W * a.H));
@@ -4258,7 +4259,8 @@ __global__ __launch_bounds__(256) void pool5_kernel(const PoolArgs a) {
 __global__ __launch_bounds__(256) void pool5_x3_kernel(const PoolArgs a) {
     const int cv = a.C / 8;
     const long total = (long)a.B * a.H * a.W * cv;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    // (single-pass launch; workgroups in XCD-contiguous order: the 5 x 5 windows of neighbouring rows meet in one L2)
+    for (long idx = (long)xcd_contiguous(blockIdx.x, gridDim.x) * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int c = (int)(idx % cv) * 8;
         const long pix = idx / cv;
         const int w = (int)(pix % a.W), h = (int)((pix / a.W) % a.H), b = (int)(pix / ((long)a.W * a.H));

@@ -40,7 +40,10 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const DwArgs a) {
     typedef typename Vec8<T>::type v8;
     const int cg = a.C / 8, xb = (a.W + DW_PX - 1) / DW_PX;
     const long total = (long)a.B * a.H * xb * cg;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    // the launch is one pass of whole workgroups; consecutive workgroups (rows y, y + 1 of an image) go to different XCDs, whose L2s
+    // would each fetch the three input rows of their outputs (PMC: 3.0 x the written bytes fetched): XCD-contiguous order instead
+    const long wg = a.xcd ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+    for (long idx = wg * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int g8 = (int)(idx % cg);
         const long pb = idx / cg;
         const int x0 = (int)(pb % xb) * DW_PX, y = (int)((pb / xb) % a.H), b = (int)(pb / ((long)xb * a.H));
@@ -134,9 +137,11 @@ hipError_t launch_dwconv(Precision p, const DwArgs& a, hipStream_t s) {
     // one pass of whole workgroups (a capped grid with a grid-stride loop leaves a ragged second round)
     const long blocks = (total + 255) / 256;
     const int grid = (int)(blocks < (1L << 22) ? blocks : (1L << 22));
-    if (p == PREC_F16) hipLaunchKernelGGL(dwconv3x3_kernel<f16>, dim3(grid), dim3(256), 0, s, a);
-    else if (p == PREC_F16X3) hipLaunchKernelGGL((dwconv3x3_kernel<f16, true>), dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(dwconv3x3_kernel<float>, dim3(grid), dim3(256), 0, s, a);
+    DwArgs a2 = a;
+    a2.xcd = blocks == grid && env_knob("CY_XCD_ORDER", 1);        // single pass only (the remap is a permutation of the launched workgroups)
+    if (p == PREC_F16) hipLaunchKernelGGL(dwconv3x3_kernel<f16>, dim3(grid), dim3(256), 0, s, a2);
+    else if (p == PREC_F16X3) hipLaunchKernelGGL((dwconv3x3_kernel<f16, true>), dim3(grid), dim3(256), 0, s, a2);
+    else hipLaunchKernelGGL(dwconv3x3_kernel<float>, dim3(grid), dim3(256), 0, s, a2);
     return hipGetLastError();
 }
 

@@ -98,6 +98,7 @@ struct DwArgs {     // depth-wise 3x3 stride 1 over NHWC channel slices; w: [9][
     const float* w; const float* bias; int B, H, W, C, act;
     int blk, gstride, goff;                            // input channel of output channel c: (c/blk)*gstride + goff + c%blk (blk = 0: c)
     int in_lo, out_lo, res_lo;                         // fp16x3 context: offsets of the low halves (see ConvArgs)
+    int xcd;                                           // set by the launch: workgroups in XCD-contiguous order
 };
 struct AttnArgs {   // softmax(q^T k * scale) applied to v, per head; qkv channels per head: [q kd | k kd | v hd]
     const void* qkv; int ct, coff; void* out; int out_ct, out_coff; int B, N, heads, kd, hd; float scale;
@@ -143,6 +144,13 @@ void pack_weights_x3(const float* W, int cout, int cin, int k, void* dst, float*
 hipError_t launch_x3_split(const float* in, void* out, long npix, int C, hipStream_t s);
 hipError_t launch_x3_merge(const void* in, float* out, long npix, int C, hipStream_t s);
 void pack_stem_weights(const float* W, int cout, void* dst);      // 64*32 fp16
+// Workgroups b and b + 8 share an XCD (round-robin dispatch over the 8 XCDs, each with its own L2): give each XCD a contiguous run of
+// work items so that neighbours in the index space (adjacent image rows of a stencil, channel blocks of the same pixels) meet in one L2.
+// Bijective for any number of workgroups.
+__device__ __forceinline__ int xcd_contiguous(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
 __host__ __device__ inline int pad64(int c) { return (c + 63) / 64 * 64; }
 __host__ __device__ inline int pad128(int c) { return (c + 127) / 128 * 128; }
 
