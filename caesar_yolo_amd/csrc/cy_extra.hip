@@ -56,8 +56,11 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const DwArgs a) {
             for (int j = 0; j < 8; ++j) acc[i][j] = a.bias[c + j];
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
+            // loads at clamped coordinates, unconditional: written as `if (inside) load`, every load sat in its own branch with a
+            // full vmcnt(0) wait behind it (18 serialised round trips per thread); the validity only gates the FMAs
             const int yy = y + kh - 1;
-            if ((unsigned)yy >= (unsigned)a.H) continue;
+            const bool rowok = (unsigned)yy < (unsigned)a.H;
+            const int yyc = yy < 0 ? 0 : (yy >= a.H ? a.H - 1 : yy);
             float w[3][8];
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw)
@@ -65,22 +68,25 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const DwArgs a) {
                 for (int j = 0; j < 8; ++j) w[kw][j] = a.w[(kh * 3 + kw) * a.C + c + j];
             float in[DW_PX + 2][8];
             bool ok[DW_PX + 2];
-            const T* row = reinterpret_cast<const T*>(a.in) + (((long)b * a.H + yy) * a.W) * a.in_ct + a.in_coff + cin;
+            const T* row = reinterpret_cast<const T*>(a.in) + (((long)b * a.H + yyc) * a.W) * a.in_ct + a.in_coff + cin;
+            v8 raw[DW_PX + 2], rawl[SPLIT ? DW_PX + 2 : 1];
 #pragma unroll
             for (int t = 0; t < DW_PX + 2; ++t) {
                 const int xx = x0 + t - 1;
-                ok[t] = (unsigned)xx < (unsigned)a.W;
-                if (ok[t]) {
-                    const T* ip = row + (long)xx * a.in_ct;
-                    const v8 v = *reinterpret_cast<const v8*>(ip);
-                    if constexpr (SPLIT) {
-                        const v8 vl = *reinterpret_cast<const v8*>(ip + a.in_lo);
+                ok[t] = rowok && (unsigned)xx < (unsigned)a.W;
+                const int xxc = xx < 0 ? 0 : (xx >= a.W ? a.W - 1 : xx);
+                const T* ip = row + (long)xxc * a.in_ct;
+                raw[t] = *reinterpret_cast<const v8*>(ip);
+                if constexpr (SPLIT) rawl[t] = *reinterpret_cast<const v8*>(ip + a.in_lo);
+            }
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) in[t][j] = (float)v[j] + (float)vl[j];
-                    } else {
+            for (int t = 0; t < DW_PX + 2; ++t) {
+                if constexpr (SPLIT) {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) in[t][j] = (float)v[j];
-                    }
+                    for (int j = 0; j < 8; ++j) in[t][j] = (float)raw[t][j] + (float)rawl[t][j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) in[t][j] = (float)raw[t][j];
                 }
             }
 #pragma unroll
