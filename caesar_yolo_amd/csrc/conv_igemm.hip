@@ -3678,13 +3678,15 @@ __global__ __launch_bounds__(256) void stem_quad_kernel(const StemArgs a) {
         for (int kh = 0; kh < 3; ++kh) {
             const int hi = ho * 2 - 1 + kh;
             const bool row_ok = (unsigned)hi < (unsigned)a.Hi;
+            const int hic = hi < 0 ? 0 : (hi >= a.Hi ? a.Hi - 1 : hi);
             vec4 r[9];
 #pragma unroll
             for (int ci = 0; ci < 9; ++ci) {
                 const int wi = wo0 * 2 - 1 + ci;
-                r[ci] = vec4{(T)0, (T)0, (T)0, (T)0};
-                if (row_ok && (unsigned)wi < (unsigned)a.Wi)
-                    r[ci] = *reinterpret_cast<const vec4*>(reinterpret_cast<const T*>(a.in) + (((long)b * a.Hi + hi) * a.Wi + wi) * 4);
+                // loaded at clamped coordinates and zeroed by a select (a conditional load is a branch with a full wait behind it)
+                const int wic = wi < 0 ? 0 : (wi >= a.Wi ? a.Wi - 1 : wi);
+                const vec4 t = *reinterpret_cast<const vec4*>(reinterpret_cast<const T*>(a.in) + (((long)b * a.Hi + hic) * a.Wi + wic) * 4);
+                r[ci] = (row_ok && (unsigned)wi < (unsigned)a.Wi) ? t : vec4{(T)0, (T)0, (T)0, (T)0};
             }
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw)
@@ -4237,20 +4239,24 @@ __global__ __launch_bounds__(256) void pool5_kernel(const PoolArgs a) {
         const int c = (int)(idx % cv) * V;
         const long pix = idx / cv;
         const int w = (int)(pix % a.W), h = (int)((pix / a.W) % a.H), b = (int)(pix / ((long)a.W * a.H));
-        vec m;
-        bool first = true;
-        for (int dh = -2; dh <= 2; ++dh)
-            for (int dw = -2; dw <= 2; ++dw) {
-                const int hh = h + dh, ww = w + dw;
-                if ((unsigned)hh >= (unsigned)a.H || (unsigned)ww >= (unsigned)a.W) continue;
-                const vec v = *reinterpret_cast<const vec*>(reinterpret_cast<const T*>(a.src) +
-                                                            (((long)b * a.H + hh) * a.W + ww) * a.ct + a.src_coff + c);
-                if (first) { m = v; first = false; }
-                else {
+        // window positions clamped into the image instead of skipped: a clamped position is another pixel of the same window, so the
+        // maximum is unchanged, and the 25 loads are unconditional (as `if (inside) load` each one had its own branch and a full wait)
+        const T* base = reinterpret_cast<const T*>(a.src) + a.src_coff + c;
+        vec m = *reinterpret_cast<const vec*>(base + (((long)b * a.H + h) * a.W + w) * a.ct);
 #pragma unroll
-                    for (int j = 0; j < V; ++j) m[j] = v[j] > m[j] ? v[j] : m[j];
-                }
+        for (int dh = -2; dh <= 2; ++dh) {
+            int hh = h + dh;
+            hh = hh < 0 ? 0 : (hh >= a.H ? a.H - 1 : hh);
+#pragma unroll
+            for (int dw = -2; dw <= 2; ++dw) {
+                if (dh == 0 && dw == 0) continue;
+                int ww = w + dw;
+                ww = ww < 0 ? 0 : (ww >= a.W ? a.W - 1 : ww);
+                const vec v = *reinterpret_cast<const vec*>(base + (((long)b * a.H + hh) * a.W + ww) * a.ct);
+#pragma unroll
+                for (int j = 0; j < V; ++j) m[j] = v[j] > m[j] ? v[j] : m[j];
             }
+        }
         *reinterpret_cast<vec*>(reinterpret_cast<T*>(a.dst) + pix * a.ct + a.dst_coff + c) = m;
     }
 }
