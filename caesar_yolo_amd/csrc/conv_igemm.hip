@@ -3202,7 +3202,9 @@ static hipError_t launch_t(const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-// detect-head output 1x1 (head1x1_kernel): which layers it takes, and its launch.  Geometry only (no batch threshold).
+// head1x1_kernel: which layers it takes, and its launch -- the detect head's output 1x1s (fp32 prediction rows, no activation) and, since
+// the end of round 4, every other single-segment 1x1 with <= 64 output channels and Cin a multiple of 64 (fp16 / split outputs into a
+// channel slice, SiLU, residual).  Geometry only (no batch threshold), so a tile's result does not depend on its batch.
 static int head_rows(const ConvArgs& a) { const int c = a.Cout < 16 ? a.Cout : 16; const int g = (c + 3) / 4; return 16 * (g < 4 ? g : 4); }
 static bool head_direct(const ConvArgs& a, int passes) {
     if (!env_knob("CY_HEAD_DIRECT", 1)) return false;             // read per call: the parity tests run both forms
